@@ -1,0 +1,164 @@
+/* rt355.h — C ABI of librt355.so: the MI355X render loop behind the reference's own entry points.
+ *
+ * The reference (Expasito/RayTracing, RayTracing/src/Source.cpp, "Src" below) has no plugin or
+ * FFI layer: its API is free functions and globals in one translation unit.  The seam this library
+ * fills is the CPU branch of the frame loop (Src:1244-1272): inputs are the `triangles` / `lights`
+ * globals, `camera.position`, the per-frame `trans` matrix, `width`, `height`; the output is the
+ * `float* data` buffer handed to glTexImage2D(GL_RGB, GL_FLOAT) at Src:1270.  Every entry point
+ * below names the reference line it replaces.  All functions return RT_OK (0) or a negative
+ * RT_ERR_* code and never exit, abort or throw across the boundary (the reference calls exit(1),
+ * Src:634-651); rt_last_error() returns a thread-local description of the last failure.
+ *
+ * There is no CPU fallback: without a HIP device rt_scene_commit / rt_render* fail with
+ * RT_ERR_DEVICE.  Scene construction (rt_scene_add_*) is host arithmetic by design — it is the
+ * reference's start-up code, and its results are what gets uploaded.
+ *
+ * Pixel layout of every framebuffer: out[(y*width + x)*3 + c], float32, c in {R,G,B}, values in
+ * [0,1], row y = 0 is the BOTTOM row of the displayed image (Src:550, 612-614, 1270).
+ */
+#ifndef RT355_H
+#define RT355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK            0
+#define RT_ERR_INVALID  -1   /* NULL / out-of-range argument                         */
+#define RT_ERR_STATE    -2   /* scene not committed, or modified since commit        */
+#define RT_ERR_DEVICE   -3   /* HIP runtime error, or no HIP device                   */
+#define RT_ERR_NOMEM    -4
+#define RT_ERR_IO       -5   /* file not found / unreadable / malformed              */
+#define RT_ERR_LIMIT    -6   /* size beyond what the chosen path supports            */
+
+/* rt_scene_commit flags: acceleration structure */
+#define RT_ACCEL_AUTO    0   /* brute force up to RT_BRUTE_AUTO_MAX triangles, LBVH above */
+#define RT_ACCEL_BRUTE   1   /* the reference's O(N) loop over every triangle (Src:301)   */
+#define RT_ACCEL_LBVH    2   /* GPU-built Morton/Karras LBVH                              */
+#define RT_BRUTE_AUTO_MAX 512
+
+/* rt_render* flags */
+#define RT_RENDER_STRICT 0   /* unfused IEEE binary32 in the reference's operation order:
+                                bit-identical frames                                         */
+#define RT_RENDER_FAST   1   /* FMA-contracted, algebraically regrouped edge tests: hit/miss
+                                may flip on grazing edges (tolerance: <=1 LSB on >=99.9 % px) */
+
+/* One triangle record as the reference stores it (Src:31-43), 28 floats:
+ * p[3] n[3] p1[3] p2[3] p3[3] edge0[3] edge1[3] edge2[3] color[3] shininess */
+#define RT_TRI_FLOATS 28
+
+typedef struct rt_scene rt_scene;
+
+/* Work counters in the units SURVEY.md §8(d) prices (filled by rt_render_stats). */
+typedef struct rt_stats {
+	uint64_t rays_primary, rays_bounce, rays_shadow;
+	uint64_t n_plane;    /* triangles visited by castRay (Src:383), 14 FLOP each           */
+	uint64_t n_point;    /* of those, not rejected by t < 0 (Src:385-389), 6 FLOP each     */
+	uint64_t n_edge;     /* edge terms evaluated with && short-circuit (Src:392-394), 17   */
+	uint64_t n_box;      /* LBVH only: ray/AABB slab tests, 22 FLOP each                   */
+	uint64_t px_hit, px_mirror, px_lit;
+} rt_stats;
+
+/* ---- scene (replaces the globals `triangles`, `lights`, Src:64-73) ------------------------ */
+
+rt_scene* rt_scene_create(void);
+void      rt_scene_destroy(rt_scene* s);
+int       rt_scene_clear(rt_scene* s);
+
+/* Triangle(p1,p2,p3,color,shininess) + triangles.push_back — Src:45-59.  color is 0..255. */
+int rt_scene_add_triangle(rt_scene* s, const float p1[3], const float p2[3], const float p3[3],
+                          const float color[3], float shininess);
+
+/* n triangles at once; arrays are n x 3 (shininess: n).  Same arithmetic as the call above. */
+int rt_scene_add_triangles(rt_scene* s, int n, const float* p1, const float* p2, const float* p3,
+                           const float* color, const float* shininess);
+
+/* addTriangle(translate, rotate_degrees, scale, color, shininess) — Src:410-439. */
+int rt_scene_add_quad_half(rt_scene* s, const float translate[3], const float rotate_deg[3],
+                           const float scale[3], const float color[3], float shininess);
+
+/* lights.push_back({position, intensity}) — Src:69-73, 880. */
+int rt_scene_add_light(rt_scene* s, const float position[3], float intensity);
+
+/* loadModel(path) — Src:631-657: "(tx, ty, tz), (rx, ry, rz), (sx, sy, sz), (r, g, b); " records,
+ * each becoming addTriangle(..., shininess 0).  Returns the number of triangles added (>= 0). */
+int rt_scene_load_rto(rt_scene* s, const char* path);
+
+int rt_scene_triangle_count(const rt_scene* s);
+int rt_scene_light_count(const rt_scene* s);
+
+/* Copy out up to `capacity` triangle records (RT_TRI_FLOATS floats each) in index order; returns
+ * the number copied.  This is the reference's `triangles` vector, for inspection and tests. */
+int rt_scene_get_triangles(const rt_scene* s, float* out28, int capacity);
+
+/* Flatten to the SoA device buffer and upload to HIP device `device` (replaces the per-frame
+ * visibleTriangles rebuild, Src:1153-1163); with RT_ACCEL_LBVH (or AUTO above the threshold)
+ * also builds the LBVH on the GPU.  Must be called again after any rt_scene_add_* / clear.
+ * A scene may be committed to several devices (one call per device). */
+int rt_scene_commit(rt_scene* s, int device, int accel_flags);
+
+/* Milliseconds the last commit on `device` spent building the LBVH on the GPU (0 for brute). */
+int rt_scene_build_ms(const rt_scene* s, int device, float* out_ms);
+
+/* The acceleration structure the last commit on `device` chose: RT_ACCEL_BRUTE or RT_ACCEL_LBVH. */
+int rt_scene_accel(const rt_scene* s, int device);
+
+/* ---- camera (Src:1145-1147) ---------------------------------------------------------------- */
+
+/* trans = rotate(rotate(I, radians(rot.x), Y), radians(-rot.y), X), column-major 4x4. */
+int rt_camera_trans(const float rot_deg[3], float out_trans16[16]);
+
+/* ---- render (replaces the getPixelData loop, Src:1248-1264 -> 530-628) --------------------- */
+
+/* Whole frame into HOST memory, synchronous: launch on the scene's device, copy back.
+ * `out_rgb` has width*height*3 floats.  max_bounces is the reference's maxBounces (Src:567: 1). */
+int rt_render(rt_scene* s, const float cam_pos[3], const float trans16[16], int width, int height,
+              int max_bounces, int render_flags, float* out_rgb);
+
+/* Whole frame into DEVICE memory, asynchronous on `hip_stream` (a hipStream_t, NULL = default
+ * stream) of device `device`.  The framebuffer stays resident in HBM for a viewer / interop. */
+int rt_render_device(rt_scene* s, int device, const float cam_pos[3], const float trans16[16],
+                     int width, int height, int max_bounces, int render_flags,
+                     float* d_out_rgb, void* hip_stream);
+
+/* Interleaved row tiles for multi-GPU sharding: renders tiles t = tile_first,
+ * tile_first + tile_stride, ... of `tile_rows` rows each (tile t covers rows [t*tile_rows,
+ * (t+1)*tile_rows)) into a COMPACT device buffer that holds only this shard's rows, in
+ * increasing y.  rt_shard_rows() tells how many rows that is. */
+int rt_render_tiles_device(rt_scene* s, int device, const float cam_pos[3], const float trans16[16],
+                           int width, int height, int max_bounces, int render_flags,
+                           int tile_rows, int tile_first, int tile_stride,
+                           float* d_out_compact, void* hip_stream);
+int rt_shard_rows(int height, int tile_rows, int tile_first, int tile_stride);
+
+/* Same frame as rt_render, additionally counting work (slower instrumented kernel). */
+int rt_render_stats(rt_scene* s, const float cam_pos[3], const float trans16[16], int width,
+                    int height, int max_bounces, float* out_rgb /* may be NULL */, rt_stats* out);
+
+/* One process, several GPUs: commits the scene to devices[0..n) if needed, renders interleaved
+ * row tiles on each and gathers the frame to host memory via devices[0]. */
+int rt_render_multi(rt_scene* s, const int* devices, int n_devices, const float cam_pos[3],
+                    const float trans16[16], int width, int height, int max_bounces,
+                    int render_flags, int tile_rows, float* out_rgb);
+
+/* castRay for a batch of rays (Src:277-405), for tests and tools: rays7 = n x {origin xyz,
+ * dir xyz, skip index (<0 = none)}; out6 = n x {didHit, index|-1, distance, point xyz}.
+ * Host pointers; synchronous. */
+int rt_cast_rays(rt_scene* s, int n_rays, const float* rays7, float* out6);
+
+/* ---- misc ---------------------------------------------------------------------------------- */
+
+int         rt_device_count(void);
+
+/* Tuning knob (process-wide): 8x8 pixel tiles each wavefront walks; 0 = library default. */
+int         rt_set_tiles_per_wave(int tiles);
+const char* rt_last_error(void);
+const char* rt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT355_H */

@@ -1,0 +1,339 @@
+"""ctypes binding of librt355.so (include/rt355.h) with the reference's own vocabulary.
+
+The reference has no plugin API: its "interface" is ``Triangle(p1,p2,p3,color,shininess)``
+(Source.cpp:45), ``addTriangle(translate, rotate, scale, color, shininess)`` (Source.cpp:410),
+``lights.push_back({pos, intensity})`` (Source.cpp:880), ``Camera(pos, rot)`` (Source.cpp:810),
+the per-frame ``trans`` (Source.cpp:1145-1147) and the loop over ``getPixelData`` that fills
+``float data[h*w*3]`` (Source.cpp:1248-1264).  :class:`Scene` offers exactly those, forwarding
+every call to the C ABI; nothing is computed in Python and there is no CPU fallback — a missing
+library or a missing GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Iterable, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt355.so")
+
+RT_OK = 0
+ACCEL_AUTO, ACCEL_BRUTE, ACCEL_LBVH = 0, 1, 2
+STRICT, FAST = 0, 1
+TRI_FLOATS = 28
+
+ERROR_NAMES = {-1: "RT_ERR_INVALID", -2: "RT_ERR_STATE", -3: "RT_ERR_DEVICE", -4: "RT_ERR_NOMEM",
+               -5: "RT_ERR_IO", -6: "RT_ERR_LIMIT"}
+
+# every symbol include/rt355.h declares (tests check that the library exports all of them)
+SYMBOLS = (
+    "rt_scene_create", "rt_scene_destroy", "rt_scene_clear", "rt_scene_add_triangle",
+    "rt_scene_add_triangles", "rt_scene_add_quad_half", "rt_scene_add_light", "rt_scene_load_rto",
+    "rt_scene_triangle_count", "rt_scene_light_count", "rt_scene_get_triangles", "rt_scene_commit",
+    "rt_scene_build_ms", "rt_scene_accel", "rt_camera_trans", "rt_render", "rt_render_device",
+    "rt_render_tiles_device", "rt_shard_rows", "rt_render_stats", "rt_render_multi", "rt_cast_rays",
+    "rt_device_count", "rt_set_tiles_per_wave", "rt_last_error", "rt_version",
+)
+
+
+class RtError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("%s (%d): %s" % (ERROR_NAMES.get(code, "RT_ERR"), code, msg))
+        self.code = code
+
+
+class Stats(C.Structure):
+    """rt_stats — work counters in the units SURVEY.md §8(d) prices."""
+    _fields_ = [(n, C.c_uint64) for n in (
+        "rays_primary", "rays_bounce", "rays_shadow", "n_plane", "n_point", "n_edge", "n_box",
+        "px_hit", "px_mirror", "px_lit")]
+
+    def as_dict(self) -> dict:
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+    @property
+    def rays(self) -> int:
+        return int(self.rays_primary + self.rays_bounce + self.rays_shadow)
+
+    @property
+    def flops(self) -> float:
+        """14 plane + 6 point + 17 edge + 22 box + 32/29/30 per primary/bounce/shadow ray."""
+        return (14.0 * self.n_plane + 6.0 * self.n_point + 17.0 * self.n_edge + 22.0 * self.n_box +
+                32.0 * self.rays_primary + 29.0 * self.rays_bounce + 30.0 * self.rays_shadow)
+
+
+_fp = C.POINTER(C.c_float)
+_lib = None
+
+
+def lib():
+    """Load librt355.so.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: build it with `make -C raytracing_amd/csrc` "
+                          "(or __graft_entry__.build()); there is no fallback path" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    L.rt_scene_create.restype = vp
+    L.rt_scene_create.argtypes = []
+    L.rt_scene_destroy.restype = None
+    L.rt_scene_destroy.argtypes = [vp]
+    L.rt_scene_clear.argtypes = [vp]
+    L.rt_scene_add_triangle.argtypes = [vp, _fp, _fp, _fp, _fp, cf]
+    L.rt_scene_add_triangles.argtypes = [vp, ci, _fp, _fp, _fp, _fp, _fp]
+    L.rt_scene_add_quad_half.argtypes = [vp, _fp, _fp, _fp, _fp, cf]
+    L.rt_scene_add_light.argtypes = [vp, _fp, cf]
+    L.rt_scene_load_rto.argtypes = [vp, C.c_char_p]
+    L.rt_scene_triangle_count.argtypes = [vp]
+    L.rt_scene_light_count.argtypes = [vp]
+    L.rt_scene_get_triangles.argtypes = [vp, _fp, ci]
+    L.rt_scene_commit.argtypes = [vp, ci, ci]
+    L.rt_scene_build_ms.argtypes = [vp, ci, _fp]
+    L.rt_scene_accel.argtypes = [vp, ci]
+    L.rt_camera_trans.argtypes = [_fp, _fp]
+    L.rt_render.argtypes = [vp, _fp, _fp, ci, ci, ci, ci, _fp]
+    L.rt_render_device.argtypes = [vp, ci, _fp, _fp, ci, ci, ci, ci, vp, vp]
+    L.rt_render_tiles_device.argtypes = [vp, ci, _fp, _fp, ci, ci, ci, ci, ci, ci, ci, vp, vp]
+    L.rt_shard_rows.argtypes = [ci, ci, ci, ci]
+    L.rt_render_stats.argtypes = [vp, _fp, _fp, ci, ci, ci, _fp, C.POINTER(Stats)]
+    L.rt_render_multi.argtypes = [vp, C.POINTER(ci), ci, _fp, _fp, ci, ci, ci, ci, ci, _fp]
+    L.rt_cast_rays.argtypes = [vp, ci, _fp, _fp]
+    L.rt_device_count.argtypes = []
+    L.rt_set_tiles_per_wave.argtypes = [ci]
+    L.rt_last_error.restype = C.c_char_p
+    L.rt_last_error.argtypes = []
+    L.rt_version.restype = C.c_char_p
+    L.rt_version.argtypes = []
+    for name in SYMBOLS:
+        getattr(L, name)          # AttributeError here == the library is older than the header
+    _lib = L
+    return L
+
+
+def _check(rc: int) -> int:
+    if rc < 0:
+        raise RtError(rc, lib().rt_last_error().decode("utf-8", "replace"))
+    return rc
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(_fp)
+
+
+def device_count() -> int:
+    return int(lib().rt_device_count())
+
+
+def camera_trans(rot_deg: Sequence[float]) -> np.ndarray:
+    """trans = rotate(rotate(I, radians(rot.x), Y), radians(-rot.y), X) — Source.cpp:1145-1147."""
+    r = _f32(rot_deg)
+    out = np.zeros(16, dtype=np.float32)
+    _check(lib().rt_camera_trans(_p(r), _p(out)))
+    return out
+
+
+def shard_rows(height: int, tile_rows: int, tile_first: int, tile_stride: int) -> int:
+    return int(lib().rt_shard_rows(height, tile_rows, tile_first, tile_stride))
+
+
+class Camera:
+    """Camera(position, rotations_deg) — Source.cpp:95-142 (pose only; the WASD controller is
+    outside the render path)."""
+
+    def __init__(self, position=(-5.0, 5.0, 5.0), rotations=(135.0, -45.0, 0.0)):
+        self.position = tuple(float(x) for x in position)
+        self.rotations = tuple(float(x) for x in rotations)
+
+    def trans(self) -> np.ndarray:
+        return camera_trans(self.rotations)
+
+
+class Scene:
+    """The reference's globals `triangles` / `lights` (Source.cpp:64-73) behind a handle."""
+
+    def __init__(self):
+        self._h = lib().rt_scene_create()
+        if not self._h:
+            raise RtError(-4, lib().rt_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rt_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- construction: the reference's entry points ------------------------------------------
+    def Triangle(self, p1, p2, p3, color, shininess=0.0) -> "Scene":
+        """triangles.push_back(Triangle(p1, p2, p3, color, shininess)) — Source.cpp:45-59."""
+        a, b, c, d = _f32(p1), _f32(p2), _f32(p3), _f32(color)
+        _check(lib().rt_scene_add_triangle(self._h, _p(a), _p(b), _p(c), _p(d), float(shininess)))
+        return self
+
+    def addTriangle(self, translate, rotate, scale, color, shininess=0.0) -> "Scene":
+        """addTriangle(translate, rotate_deg, scale, color, shininess) — Source.cpp:410-439."""
+        a, b, c, d = _f32(translate), _f32(rotate), _f32(scale), _f32(color)
+        _check(lib().rt_scene_add_quad_half(self._h, _p(a), _p(b), _p(c), _p(d), float(shininess)))
+        return self
+
+    def addTriangles(self, p1, p2, p3, color, shininess) -> "Scene":
+        a, b, c, d, e = _f32(p1), _f32(p2), _f32(p3), _f32(color), _f32(shininess)
+        n = a.shape[0]
+        if not (a.shape == b.shape == c.shape == d.shape == (n, 3) and e.shape == (n,)):
+            raise ValueError("addTriangles wants (n,3) x4 and (n,)")
+        _check(lib().rt_scene_add_triangles(self._h, n, _p(a), _p(b), _p(c), _p(d), _p(e)))
+        return self
+
+    def addLight(self, position, intensity) -> "Scene":
+        """lights.push_back({position, intensity}) — Source.cpp:880."""
+        a = _f32(position)
+        _check(lib().rt_scene_add_light(self._h, _p(a), float(intensity)))
+        return self
+
+    def loadModel(self, path: str) -> int:
+        """loadModel(path) — Source.cpp:631-657 (.rto text records)."""
+        return _check(lib().rt_scene_load_rto(self._h, os.fsencode(path)))
+
+    def clear(self) -> "Scene":
+        _check(lib().rt_scene_clear(self._h))
+        return self
+
+    @classmethod
+    def from_desc(cls, desc) -> "Scene":
+        """Replays a scenes.SceneDesc (ordered reference calls) through the C ABI."""
+        sc = cls()
+        run = []   # consecutive `tri` ops go through the bulk entry point
+
+        def flush():
+            if run:
+                v = np.asarray(run, dtype=np.float32)
+                sc.addTriangles(v[:, 0:3], v[:, 3:6], v[:, 6:9], v[:, 9:12], v[:, 12])
+                run.clear()
+
+        for kind, v in desc.ops:
+            if kind == "tri":
+                run.append(v)
+                continue
+            flush()
+            if kind == "quadhalf":
+                sc.addTriangle(v[0:3], v[3:6], v[6:9], v[9:12], v[12])
+            elif kind == "light":
+                sc.addLight(v[0:3], v[3])
+            else:
+                raise ValueError("unknown scene op %r" % (kind,))
+        flush()
+        return sc
+
+    # -- inspection -----------------------------------------------------------------------------
+    @property
+    def n_triangles(self) -> int:
+        return _check(lib().rt_scene_triangle_count(self._h))
+
+    @property
+    def n_lights(self) -> int:
+        return _check(lib().rt_scene_light_count(self._h))
+
+    def triangles(self) -> np.ndarray:
+        """(N, 28) float32 — the reference's Triangle records (p n p1 p2 p3 edge0..2 color shin)."""
+        n = self.n_triangles
+        out = np.zeros((n, TRI_FLOATS), dtype=np.float32)
+        if n:
+            _check(lib().rt_scene_get_triangles(self._h, _p(out), n))
+        return out
+
+    # -- device ---------------------------------------------------------------------------------
+    def commit(self, device: int = 0, accel: int = ACCEL_AUTO) -> "Scene":
+        _check(lib().rt_scene_commit(self._h, int(device), int(accel)))
+        return self
+
+    def accel(self, device: int = 0) -> int:
+        return _check(lib().rt_scene_accel(self._h, int(device)))
+
+    def build_ms(self, device: int = 0) -> float:
+        ms = C.c_float(0)
+        _check(lib().rt_scene_build_ms(self._h, int(device), C.byref(ms)))
+        return float(ms.value)
+
+    # -- render: replaces the getPixelData loop -------------------------------------------------
+    def render(self, cam_pos, trans16, width: int, height: int, max_bounces: int = 1,
+               mode: int = STRICT) -> np.ndarray:
+        """(H, W, 3) float32, data[(y*w+x)*3+c], row 0 = bottom — Source.cpp:550, 612-614."""
+        cam, tr = _f32(cam_pos), _f32(trans16)
+        out = np.empty((height, width, 3), dtype=np.float32)
+        _check(lib().rt_render(self._h, _p(cam), _p(tr), width, height, max_bounces, mode, _p(out)))
+        return out
+
+    def render_stats(self, cam_pos, trans16, width: int, height: int, max_bounces: int = 1,
+                     want_frame: bool = True):
+        cam, tr = _f32(cam_pos), _f32(trans16)
+        out = np.empty((height, width, 3), dtype=np.float32) if want_frame else None
+        st = Stats()
+        _check(lib().rt_render_stats(self._h, _p(cam), _p(tr), width, height, max_bounces,
+                                     _p(out) if want_frame else None, C.byref(st)))
+        return out, st
+
+    def render_device(self, device: int, cam_pos, trans16, width: int, height: int, max_bounces: int,
+                      mode: int, d_out_ptr: int, stream: int = 0) -> None:
+        """Asynchronous launch into caller-owned device memory (raw pointer, e.g. tensor.data_ptr())."""
+        cam, tr = _f32(cam_pos), _f32(trans16)
+        _check(lib().rt_render_device(self._h, device, _p(cam), _p(tr), width, height, max_bounces, mode,
+                                      C.c_void_p(d_out_ptr), C.c_void_p(stream)))
+
+    def render_tiles_device(self, device: int, cam_pos, trans16, width: int, height: int, max_bounces: int,
+                            mode: int, tile_rows: int, tile_first: int, tile_stride: int,
+                            d_out_ptr: int, stream: int = 0) -> None:
+        cam, tr = _f32(cam_pos), _f32(trans16)
+        _check(lib().rt_render_tiles_device(self._h, device, _p(cam), _p(tr), width, height, max_bounces, mode,
+                                            tile_rows, tile_first, tile_stride,
+                                            C.c_void_p(d_out_ptr), C.c_void_p(stream)))
+
+    def render_multi(self, devices: Iterable[int], cam_pos, trans16, width: int, height: int,
+                     max_bounces: int = 1, mode: int = STRICT, tile_rows: int = 16) -> np.ndarray:
+        devs = (C.c_int * len(list(devices)))(*list(devices))
+        cam, tr = _f32(cam_pos), _f32(trans16)
+        out = np.empty((height, width, 3), dtype=np.float32)
+        _check(lib().rt_render_multi(self._h, devs, len(devs), _p(cam), _p(tr), width, height, max_bounces,
+                                     mode, tile_rows, _p(out)))
+        return out
+
+    def cast_rays(self, rays7) -> np.ndarray:
+        """castRay for K rays (Source.cpp:277-405): rays7 (K,7) = origin, dir, skip index (<0 none)
+        -> (K,6) = didHit, index|-1, distance, point."""
+        r = _f32(rays7).reshape(-1, 7)
+        out = np.zeros((r.shape[0], 6), dtype=np.float32)
+        _check(lib().rt_cast_rays(self._h, r.shape[0], _p(r), _p(out)))
+        return out
+
+
+def render_desc(desc, device: int = 0, accel: int = ACCEL_AUTO, mode: int = STRICT) -> np.ndarray:
+    """Scene description -> frame, the way the reference's main() would: build, commit, render."""
+    with Scene.from_desc(desc) as sc:
+        sc.commit(device, accel)
+        return sc.render(desc.cam_pos, camera_trans(desc.cam_rot), desc.width, desc.height, desc.depth, mode)
+
+
+def quantize(rgb: np.ndarray) -> np.ndarray:
+    """The GL unorm rule both sides of every 8-bit comparison use:
+    q = (int)(c*255.0f + 0.5f), c<0 or NaN -> 0, c>1 -> 255."""
+    c = np.asarray(rgb, dtype=np.float32)
+    c = np.where(c > 0, c, np.float32(0))          # NaN and negatives -> 0
+    c = np.minimum(c, np.float32(1))
+    return (c * np.float32(255.0) + np.float32(0.5)).astype(np.int32).astype(np.uint8)

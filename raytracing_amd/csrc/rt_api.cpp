@@ -1,0 +1,380 @@
+// rt_api.cpp — host side of the C ABI (include/rt355.h): device state, upload, launches, copies.
+//
+// This is where the reference's frame loop hands over (Source.cpp:1244-1272): instead of calling
+// getPixelData W*H times it calls rt_render*, and gets back the same `float data[h*w*3]`.
+// There is no CPU rendering path in this library: without a HIP device every entry point below
+// returns RT_ERR_DEVICE.
+#include "rt_internal.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace rt {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof g_err, fmt, ap);
+	va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char* what) {
+	set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
+	(void)hipGetLastError();   // clear the sticky last-error slot
+	return e == hipErrorOutOfMemory ? RT_ERR_NOMEM : RT_ERR_DEVICE;
+}
+
+namespace {
+
+// Makes `device` current for the scope and restores the caller's device afterwards.
+struct DeviceGuard {
+	int prev = -1;
+	bool ok = false;
+	int rc = RT_OK;
+	explicit DeviceGuard(int device) {
+		int n = 0;
+		hipError_t e = hipGetDeviceCount(&n);
+		if (e != hipSuccess || n <= 0) {
+			(void)hipGetLastError();
+			set_error("no HIP device available (hipGetDeviceCount: %s); this library has no CPU path", hipGetErrorString(e));
+			rc = RT_ERR_DEVICE;
+			return;
+		}
+		if (device < 0 || device >= n) {
+			set_error("device %d out of range (have %d)", device, n);
+			rc = RT_ERR_INVALID;
+			return;
+		}
+		if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+		e = hipSetDevice(device);
+		if (e != hipSuccess) { rc = hip_fail(e, "hipSetDevice"); return; }
+		ok = true;
+	}
+	~DeviceGuard() {
+		if (ok && prev >= 0) (void)hipSetDevice(prev);
+	}
+};
+
+void free_device_state(DeviceState& d) {
+	if (d.device < 0) return;
+	int prev = -1;
+	(void)hipGetDevice(&prev);
+	if (hipSetDevice(d.device) == hipSuccess) {
+		if (d.planes) (void)hipFree(d.planes);
+		if (d.lights) (void)hipFree(d.lights);
+		if (d.counters) (void)hipFree(d.counters);
+		if (d.frame) (void)hipFree(d.frame);
+		lbvh_free(d);
+	}
+	if (prev >= 0) (void)hipSetDevice(prev);
+	d = DeviceState();
+}
+
+int check_frame_args(const char* fn, const rt_scene* s, const float* cam, const float* trans, int w, int h, int depth) {
+	if (!s || !cam || !trans) { set_error("%s: NULL argument", fn); return RT_ERR_INVALID; }
+	if (w <= 0 || h <= 0) { set_error("%s: width and height must be positive (got %dx%d)", fn, w, h); return RT_ERR_INVALID; }
+	if ((long long)w * h > 0x7fffffffLL / 3) { set_error("%s: %dx%d overflows the reference's int pixel index (Source.cpp:550)", fn, w, h); return RT_ERR_LIMIT; }
+	if (depth < 0) { set_error("%s: max_bounces must be >= 0", fn); return RT_ERR_INVALID; }
+	return RT_OK;
+}
+
+DeviceState* committed(const char* fn, rt_scene* s, int device) {
+	auto it = s->dev.find(device);
+	if (it == s->dev.end() || !it->second.valid) {
+		set_error("%s: scene is not committed on device %d (rt_scene_commit after the last rt_scene_add_*)", fn, device);
+		return nullptr;
+	}
+	return &it->second;
+}
+
+void fill_frame(FrameParams& fp, const float cam[3], const float trans16[16], int w, int h, int depth) {
+	memcpy(fp.cam, cam, sizeof fp.cam);
+	memcpy(fp.m, trans16, sizeof fp.m);
+	fp.width = w;
+	fp.height = h;
+	fp.max_bounces = depth;
+	fp.tile_rows = h;
+	fp.tile_first = 0;
+	fp.tile_stride = 1;
+	fp.local_rows = h;
+	fp.tiles_per_wave = 0;
+	fp.out = nullptr;
+	fp.counters = nullptr;
+}
+
+int ensure_frame(DeviceState& d, size_t bytes) {
+	if (d.frame_bytes >= bytes) return RT_OK;
+	if (d.frame) { (void)hipFree(d.frame); d.frame = nullptr; d.frame_bytes = 0; }
+	RT_HIP(hipMalloc(&d.frame, bytes));
+	d.frame_bytes = bytes;
+	return RT_OK;
+}
+
+int g_tiles_per_wave_override = 0;
+
+} // namespace
+} // namespace rt
+
+using namespace rt;
+
+extern "C" {
+
+void rt_scene_destroy(rt_scene* s) {
+	if (!s) return;
+	for (auto& kv : s->dev) free_device_state(kv.second);
+	delete s;
+}
+
+int rt_device_count(void) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+	return n;
+}
+
+const char* rt_last_error(void) { return g_err; }
+const char* rt_version(void) { return "rt355 0.1 (gfx950)"; }
+
+int rt_set_tiles_per_wave(int tiles) {
+	g_tiles_per_wave_override = tiles < 0 ? 0 : tiles;
+	return RT_OK;
+}
+
+int rt_scene_commit(rt_scene* s, int device, int accel_flags) {
+	if (!s) { set_error("rt_scene_commit: NULL scene"); return RT_ERR_INVALID; }
+	if (accel_flags != RT_ACCEL_AUTO && accel_flags != RT_ACCEL_BRUTE && accel_flags != RT_ACCEL_LBVH) {
+		set_error("rt_scene_commit: unknown accel flag %d", accel_flags);
+		return RT_ERR_INVALID;
+	}
+	DeviceGuard g(device);
+	if (!g.ok) return g.rc;
+	DeviceState& d = s->dev[device];
+	if (d.device >= 0) free_device_state(d);
+	d.device = device;
+	const int n = (int)(s->tris.size() / RT_TRI_FLOATS);
+	const int nl = (int)(s->lights.size() / 4);
+	d.stride = ((n > 0 ? n : 1) + 63) / 64 * 64;
+	std::vector<float> planes;
+	try { flatten_planes(s->tris, d.stride, planes); } catch (...) { set_error("rt_scene_commit: out of host memory"); return RT_ERR_NOMEM; }
+	RT_HIP(hipMalloc(&d.planes, planes.size() * sizeof(float)));
+	RT_HIP(hipMemcpy(d.planes, planes.data(), planes.size() * sizeof(float), hipMemcpyHostToDevice));
+	RT_HIP(hipMalloc(&d.lights, (size_t)(nl > 0 ? nl : 1) * 4 * sizeof(float)));
+	if (nl > 0) RT_HIP(hipMemcpy(d.lights, s->lights.data(), (size_t)nl * 4 * sizeof(float), hipMemcpyHostToDevice));
+	RT_HIP(hipMalloc(&d.counters, 16 * sizeof(unsigned long long)));
+	d.accel = accel_flags == RT_ACCEL_AUTO ? (n > RT_BRUTE_AUTO_MAX ? RT_ACCEL_LBVH : RT_ACCEL_BRUTE) : accel_flags;
+	if (d.accel == RT_ACCEL_LBVH && n < 2) d.accel = RT_ACCEL_BRUTE;    // a tree needs two leaves
+	d.build_ms = 0.f;
+	if (d.accel == RT_ACCEL_LBVH) {
+		int rc = lbvh_build(s, d, nullptr);
+		if (rc != RT_OK) return rc;
+	}
+	d.valid = true;
+	if (s->first_device < 0 || !s->dev.count(s->first_device) || !s->dev[s->first_device].valid) s->first_device = device;
+	return RT_OK;
+}
+
+int rt_scene_build_ms(const rt_scene* s, int device, float* out_ms) {
+	if (!s || !out_ms) { set_error("rt_scene_build_ms: NULL argument"); return RT_ERR_INVALID; }
+	auto it = s->dev.find(device);
+	if (it == s->dev.end() || !it->second.valid) { set_error("rt_scene_build_ms: not committed on device %d", device); return RT_ERR_STATE; }
+	*out_ms = it->second.build_ms;
+	return RT_OK;
+}
+
+int rt_scene_accel(const rt_scene* s, int device) {
+	if (!s) { set_error("rt_scene_accel: NULL scene"); return RT_ERR_INVALID; }
+	auto it = s->dev.find(device);
+	if (it == s->dev.end() || !it->second.valid) { set_error("rt_scene_accel: not committed on device %d", device); return RT_ERR_STATE; }
+	return it->second.accel;
+}
+
+int rt_render_tiles_device(rt_scene* s, int device, const float cam_pos[3], const float trans16[16],
+                           int width, int height, int max_bounces, int render_flags,
+                           int tile_rows, int tile_first, int tile_stride,
+                           float* d_out_compact, void* hip_stream) {
+	int rc = check_frame_args("rt_render_tiles_device", s, cam_pos, trans16, width, height, max_bounces);
+	if (rc != RT_OK) return rc;
+	if (!d_out_compact) { set_error("rt_render_tiles_device: NULL output"); return RT_ERR_INVALID; }
+	if (tile_rows <= 0 || tile_first < 0 || tile_stride <= 0) { set_error("rt_render_tiles_device: bad tile parameters"); return RT_ERR_INVALID; }
+	if (render_flags != RT_RENDER_STRICT && render_flags != RT_RENDER_FAST) { set_error("rt_render_tiles_device: unknown render flag %d", render_flags); return RT_ERR_INVALID; }
+	DeviceGuard g(device);
+	if (!g.ok) return g.rc;
+	DeviceState* d = committed("rt_render_tiles_device", s, device);
+	if (!d) return RT_ERR_STATE;
+	FrameParams fp;
+	fill_frame(fp, cam_pos, trans16, width, height, max_bounces);
+	fp.tile_rows = tile_rows;
+	fp.tile_first = tile_first;
+	fp.tile_stride = tile_stride;
+	fp.local_rows = rt_shard_rows(height, tile_rows, tile_first, tile_stride);
+	fp.tiles_per_wave = g_tiles_per_wave_override;
+	fp.out = d_out_compact;
+	return launch_render(dev_scene(s, *d), fp, d->accel, render_flags, false, (hipStream_t)hip_stream);
+}
+
+int rt_shard_rows(int height, int tile_rows, int tile_first, int tile_stride) {
+	if (height <= 0 || tile_rows <= 0 || tile_first < 0 || tile_stride <= 0) return 0;
+	int rows = 0;
+	for (long long t = tile_first; t * tile_rows < height; t += tile_stride) {
+		long long r0 = t * tile_rows, r1 = r0 + tile_rows;
+		if (r1 > height) r1 = height;
+		rows += (int)(r1 - r0);
+	}
+	return rows;
+}
+
+int rt_render_device(rt_scene* s, int device, const float cam_pos[3], const float trans16[16],
+                     int width, int height, int max_bounces, int render_flags,
+                     float* d_out_rgb, void* hip_stream) {
+	// one tile == the whole frame
+	return rt_render_tiles_device(s, device, cam_pos, trans16, width, height, max_bounces, render_flags,
+	                              height > 0 ? height : 1, 0, 1, d_out_rgb, hip_stream);
+}
+
+int rt_render(rt_scene* s, const float cam_pos[3], const float trans16[16], int width, int height,
+              int max_bounces, int render_flags, float* out_rgb) {
+	int rc = check_frame_args("rt_render", s, cam_pos, trans16, width, height, max_bounces);
+	if (rc != RT_OK) return rc;
+	if (!out_rgb) { set_error("rt_render: NULL output"); return RT_ERR_INVALID; }
+	if (s->first_device < 0) { set_error("rt_render: scene is not committed to any device"); return RT_ERR_STATE; }
+	const int device = s->first_device;
+	DeviceGuard g(device);
+	if (!g.ok) return g.rc;
+	DeviceState* d = committed("rt_render", s, device);
+	if (!d) return RT_ERR_STATE;
+	const size_t bytes = (size_t)width * height * 3 * sizeof(float);
+	rc = ensure_frame(*d, bytes);
+	if (rc != RT_OK) return rc;
+	rc = rt_render_device(s, device, cam_pos, trans16, width, height, max_bounces, render_flags, (float*)d->frame, nullptr);
+	if (rc != RT_OK) return rc;
+	RT_HIP(hipMemcpy(out_rgb, d->frame, bytes, hipMemcpyDeviceToHost));
+	return RT_OK;
+}
+
+int rt_render_stats(rt_scene* s, const float cam_pos[3], const float trans16[16], int width,
+                    int height, int max_bounces, float* out_rgb, rt_stats* out) {
+	int rc = check_frame_args("rt_render_stats", s, cam_pos, trans16, width, height, max_bounces);
+	if (rc != RT_OK) return rc;
+	if (!out) { set_error("rt_render_stats: NULL stats"); return RT_ERR_INVALID; }
+	if (s->first_device < 0) { set_error("rt_render_stats: scene is not committed to any device"); return RT_ERR_STATE; }
+	const int device = s->first_device;
+	DeviceGuard g(device);
+	if (!g.ok) return g.rc;
+	DeviceState* d = committed("rt_render_stats", s, device);
+	if (!d) return RT_ERR_STATE;
+	const size_t bytes = (size_t)width * height * 3 * sizeof(float);
+	rc = ensure_frame(*d, bytes);
+	if (rc != RT_OK) return rc;
+	RT_HIP(hipMemsetAsync(d->counters, 0, 16 * sizeof(unsigned long long), nullptr));
+	FrameParams fp;
+	fill_frame(fp, cam_pos, trans16, width, height, max_bounces);
+	fp.tiles_per_wave = g_tiles_per_wave_override;
+	fp.out = (float*)d->frame;
+	fp.counters = (unsigned long long*)d->counters;
+	rc = launch_render(dev_scene(s, *d), fp, d->accel, RT_RENDER_STRICT, true, nullptr);
+	if (rc != RT_OK) return rc;
+	unsigned long long c[16];
+	RT_HIP(hipMemcpy(c, d->counters, sizeof c, hipMemcpyDeviceToHost));
+	if (out_rgb) RT_HIP(hipMemcpy(out_rgb, d->frame, bytes, hipMemcpyDeviceToHost));
+	out->rays_primary = c[0]; out->rays_bounce = c[1]; out->rays_shadow = c[2];
+	out->n_plane = c[3]; out->n_point = c[4]; out->n_edge = c[5]; out->n_box = c[6];
+	out->px_hit = c[7]; out->px_mirror = c[8]; out->px_lit = c[9];
+	return RT_OK;
+}
+
+int rt_render_multi(rt_scene* s, const int* devices, int n_devices, const float cam_pos[3],
+                    const float trans16[16], int width, int height, int max_bounces,
+                    int render_flags, int tile_rows, float* out_rgb) {
+	int rc = check_frame_args("rt_render_multi", s, cam_pos, trans16, width, height, max_bounces);
+	if (rc != RT_OK) return rc;
+	if (!devices || n_devices <= 0 || !out_rgb || tile_rows <= 0) { set_error("rt_render_multi: bad argument"); return RT_ERR_INVALID; }
+	for (int a = 0; a < n_devices; a++)
+		for (int b = a + 1; b < n_devices; b++)
+			if (devices[a] == devices[b]) { set_error("rt_render_multi: device %d listed twice", devices[a]); return RT_ERR_INVALID; }
+	// 1. commit where needed (keeps the acceleration choice of the first committed device)
+	int accel = RT_ACCEL_AUTO;
+	for (int k = 0; k < n_devices; k++) {
+		auto it = s->dev.find(devices[k]);
+		if (it != s->dev.end() && it->second.valid) { accel = it->second.accel; break; }
+	}
+	for (int k = 0; k < n_devices; k++) {
+		auto it = s->dev.find(devices[k]);
+		if (it == s->dev.end() || !it->second.valid) {
+			rc = rt_scene_commit(s, devices[k], accel);
+			if (rc != RT_OK) return rc;
+		}
+	}
+	// 2. every device renders its interleaved row tiles into a compact buffer (its scratch frame)
+	const size_t row_bytes = (size_t)width * 3 * sizeof(float);
+	std::vector<hipStream_t> streams((size_t)n_devices, nullptr);
+	auto cleanup = [&]() {
+		for (int k = 0; k < n_devices; k++)
+			if (streams[k]) { (void)hipSetDevice(devices[k]); (void)hipStreamDestroy(streams[k]); }
+	};
+	int prev = -1;
+	(void)hipGetDevice(&prev);
+	for (int k = 0; k < n_devices && rc == RT_OK; k++) {
+		DeviceState& d = s->dev[devices[k]];
+		const int rows = rt_shard_rows(height, tile_rows, k, n_devices);
+		if (hipSetDevice(devices[k]) != hipSuccess) { rc = RT_ERR_DEVICE; set_error("rt_render_multi: hipSetDevice(%d) failed", devices[k]); break; }
+		if (hipStreamCreateWithFlags(&streams[k], hipStreamNonBlocking) != hipSuccess) { rc = RT_ERR_DEVICE; set_error("rt_render_multi: stream creation failed"); break; }
+		if (rows == 0) continue;
+		rc = ensure_frame(d, (size_t)rows * row_bytes);
+		if (rc != RT_OK) break;
+		rc = rt_render_tiles_device(s, devices[k], cam_pos, trans16, width, height, max_bounces, render_flags,
+		                            tile_rows, k, n_devices, (float*)d.frame, streams[k]);
+	}
+	// 3. gather: each shard's tiles go straight to their rows of the caller's frame
+	for (int k = 0; k < n_devices && rc == RT_OK; k++) {
+		DeviceState& d = s->dev[devices[k]];
+		(void)hipSetDevice(devices[k]);
+		size_t src_row = 0;
+		for (long long t = k; t * tile_rows < height && rc == RT_OK; t += n_devices) {
+			long long r0 = t * tile_rows, r1 = r0 + tile_rows;
+			if (r1 > height) r1 = height;
+			hipError_t e = hipMemcpyAsync((char*)out_rgb + (size_t)r0 * row_bytes, (const char*)d.frame + src_row * row_bytes,
+			                              (size_t)(r1 - r0) * row_bytes, hipMemcpyDeviceToHost, streams[k]);
+			if (e != hipSuccess) rc = hip_fail(e, "rt_render_multi gather");
+			src_row += (size_t)(r1 - r0);
+		}
+	}
+	for (int k = 0; k < n_devices; k++) {
+		if (!streams[k]) continue;
+		(void)hipSetDevice(devices[k]);
+		hipError_t e = hipStreamSynchronize(streams[k]);
+		if (e != hipSuccess && rc == RT_OK) rc = hip_fail(e, "rt_render_multi sync");
+	}
+	cleanup();
+	if (prev >= 0) (void)hipSetDevice(prev);
+	return rc;
+}
+
+int rt_cast_rays(rt_scene* s, int n_rays, const float* rays7, float* out6) {
+	if (!s || n_rays < 0 || (n_rays > 0 && (!rays7 || !out6))) { set_error("rt_cast_rays: bad argument"); return RT_ERR_INVALID; }
+	if (s->first_device < 0) { set_error("rt_cast_rays: scene is not committed to any device"); return RT_ERR_STATE; }
+	if (n_rays == 0) return RT_OK;
+	const int device = s->first_device;
+	DeviceGuard g(device);
+	if (!g.ok) return g.rc;
+	DeviceState* d = committed("rt_cast_rays", s, device);
+	if (!d) return RT_ERR_STATE;
+	float *dr = nullptr, *dout = nullptr;
+	RT_HIP(hipMalloc((void**)&dr, (size_t)n_rays * 7 * sizeof(float)));
+	hipError_t e = hipMalloc((void**)&dout, (size_t)n_rays * 6 * sizeof(float));
+	if (e != hipSuccess) { (void)hipFree(dr); return hip_fail(e, "hipMalloc"); }
+	int rc = RT_OK;
+	e = hipMemcpy(dr, rays7, (size_t)n_rays * 7 * sizeof(float), hipMemcpyHostToDevice);
+	if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy rays");
+	if (rc == RT_OK) rc = launch_cast_rays(dev_scene(s, *d), d->accel, n_rays, dr, dout, nullptr);
+	if (rc == RT_OK) {
+		e = hipMemcpy(out6, dout, (size_t)n_rays * 6 * sizeof(float), hipMemcpyDeviceToHost);
+		if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy hits");
+	}
+	(void)hipFree(dr);
+	(void)hipFree(dout);
+	return rc;
+}
+
+} // extern "C"

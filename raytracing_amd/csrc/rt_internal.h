@@ -1,0 +1,114 @@
+// rt_internal.h — types shared by the host side (rt_api.cpp, rt_scene.cpp) and the kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/rt355.h"
+#include "rt_vec.h"
+
+namespace rt {
+
+// ---- device scene: SoA of float4 planes in HBM -------------------------------------------------
+// plane k of triangle i lives at planes[k * stride + i]  (stride = triangle count rounded up to 64
+// so every plane starts 1 KiB-aligned and a wave's 64 x 16 B staging loads are fully coalesced).
+//   plane 0  N  = (n.x,  n.y,  n.z,  shininess)         Source.cpp:34, 43
+//   plane 1  P1 = (p1.x, p1.y, p1.z, color.r)           Source.cpp:36, 41
+//   plane 2  P2 = (p2.x, p2.y, p2.z, color.g)
+//   plane 3  P3 = (p3.x, p3.y, p3.z, color.b)
+//   plane 4  E0 = (edge0.xyz, 0)                        Source.cpp:52
+//   plane 5  E1 = (edge1.xyz, 0)                        Source.cpp:53
+//   plane 6  E2 = (edge2.xyz, 0)                        Source.cpp:54
+// The `p` field of the reference record (Source.cpp:33, always == p1) is not uploaded.
+enum { PL_N = 0, PL_P1, PL_P2, PL_P3, PL_E0, PL_E1, PL_E2, PL_COUNT };
+
+// Brute force keeps the whole scene in LDS up to this many triangles (7 planes x 16 B x 512 =
+// 56 KiB, under the 64 KiB a workgroup gets without opting in to more); above it the brute-force
+// kernel reads the planes from global memory / L2 instead.
+#define RT_LDS_MAX_TRIS 512
+
+struct DevScene {
+	const float4* planes;   // PL_COUNT * stride float4
+	const float4* lights;   // n_lights x (pos.xyz, intensity)   Source.cpp:69-73
+	int n_tris;
+	int stride;
+	int n_lights;
+	int pad;
+	// LBVH (null for brute force): see rt_lbvh.hip
+	const float4* bvh_nodes;
+	const int* bvh_prim;
+	int bvh_root;
+	int pad2;
+};
+
+// Per-launch frame description.  Rows are addressed as LOCAL rows of this shard:
+// local row ly -> tile ly / tile_rows -> global tile tile_first + that * tile_stride ->
+// global row y = tile * tile_rows + ly % tile_rows.  A whole frame is tile_first 0, stride 1.
+struct FrameParams {
+	float cam[3];           // camera.position            Source.cpp:545
+	float m[16];            // trans, column-major        Source.cpp:1145-1147
+	int width, height;      // Source.cpp:887-888
+	int max_bounces;        // Source.cpp:567
+	int tile_rows, tile_first, tile_stride;
+	int local_rows;         // rows this launch renders
+	int tiles_per_wave;     // 8x8 pixel tiles per wavefront, 0 = let the launcher choose
+	float* out;             // local_rows * width * 3 floats
+	unsigned long long* counters;   // rt_stats as 10 x u64, or null
+};
+
+// ---- host scene ------------------------------------------------------------------------------
+
+struct DeviceState {
+	int device = -1;
+	bool valid = false;
+	int accel = RT_ACCEL_BRUTE;
+	void* planes = nullptr;
+	void* lights = nullptr;
+	void* bvh_nodes = nullptr;
+	void* bvh_prim = nullptr;
+	void* counters = nullptr;
+	int bvh_root = 0;
+	int stride = 0;
+	float build_ms = 0.f;
+	// scratch framebuffer for rt_render (host output)
+	void* frame = nullptr;
+	size_t frame_bytes = 0;
+	void* pinned = nullptr;
+	size_t pinned_bytes = 0;
+};
+
+} // namespace rt
+
+struct rt_scene {
+	std::vector<float> tris;      // RT_TRI_FLOATS per triangle, the reference's record
+	std::vector<float> lights;    // 4 per light
+	unsigned long long generation = 1;
+	std::map<int, rt::DeviceState> dev;   // by HIP device ordinal
+	int first_device = -1;
+};
+
+namespace rt {
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+#define RT_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return rt::hip_fail(e_, #call); } while (0)
+
+// rt_scene.cpp
+void triangle_record(vec3 p1, vec3 p2, vec3 p3, vec3 color, float shin, float* out28);
+void quad_half_record(const float T[3], const float Rdeg[3], const float S[3], const float color[3], float shin, float* out28);
+void camera_trans(const float rot_deg[3], float out16[16]);
+void flatten_planes(const std::vector<float>& tris, int stride, std::vector<float>& out);
+
+// rt_kernels.hip
+DevScene dev_scene(const rt_scene* s, const DeviceState& d);
+int launch_render(const DevScene& sc, const FrameParams& fp, int accel, int render_flags, bool count, hipStream_t stream);
+int launch_cast_rays(const DevScene& sc, int accel, int n, const float* d_rays7, float* d_out6, hipStream_t stream);
+
+// rt_lbvh.hip
+int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream);
+void lbvh_free(DeviceState& d);
+
+} // namespace rt

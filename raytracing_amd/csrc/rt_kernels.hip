@@ -1,0 +1,446 @@
+// rt_kernels.hip — the per-pixel render loop of the reference (getPixelData Source.cpp:530-628,
+// castRay Source.cpp:277-405, processLighting Source.cpp:460-494) as ONE fused gfx950 kernel.
+//
+// Shape of the kernel (MI355X-first, not the reference's call tree):
+//   * one lane == one pixel at a time; a wavefront (64 lanes) walks 8x8 pixel tiles;
+//   * the scene's float4 SoA planes are staged once per workgroup into LDS and every lane of the
+//     wave reads the SAME triangle per loop trip (one broadcast ds_read_b128 per plane);
+//   * the reference's recursion-by-call (primary castRay -> mirror loop castRays -> per-light
+//     shadow castRays) is flattened into a per-lane state machine with ONE closest-hit loop in the
+//     instruction stream: a lane holds "the ray it is waiting on" (primary, bounce or shadow) and
+//     all 64 lanes sit in that one loop together whatever their stage is;
+//   * lanes whose pixel is finished are refilled with fresh pixels from the wave's tile run using
+//     ballot + mbcnt prefix ranks ("ray regeneration"), so bounce-depth divergence (config 3:
+//     0..16 loop trips per pixel) compacts itself instead of idling lanes.
+//
+// Numerics: this TU is compiled with -ffp-contract=off.  STRICT kernels use only unfused binary32
+// + - * / sqrt in the reference's order (and binary64 at the two places the reference does) and
+// therefore reproduce the CPU frames bit for bit.  FAST kernels (explicit fmaf / rcp, regrouped
+// edge tests) are in rt_fast.inl.
+#include "rt_internal.h"
+
+namespace rt {
+
+// Source.cpp:391 compares `t > 0.00001` with t promoted to double.  For a binary32 t this is the
+// same predicate as t > EPS_BELOW where EPS_BELOW is the largest binary32 <= 0.00001 (double):
+// (float)0.00001 = 0x3727C5AC = 9.99999974737875e-06 < 1e-5, so that float itself.
+#define RT_EPS_BELOW 9.99999974737875163555145263671875e-06f
+static_assert((double)RT_EPS_BELOW <= 0.00001, "EPS_BELOW must not exceed the double literal");
+
+enum { ST_IDLE = 0, ST_PRIMARY = 1, ST_BOUNCE = 2, ST_SHADOW = 3 };
+enum { CTR_PRIMARY = 0, CTR_BOUNCE, CTR_SHADOW, CTR_PLANE, CTR_POINT, CTR_EDGE, CTR_BOX, CTR_PXHIT, CTR_PXMIRROR, CTR_PXLIT, CTR_N };
+
+struct Hit {
+	float t;      // closest.distance, 1e9f when nothing was hit (Source.cpp:278)
+	int idx;      // closest.cur as an index, -1 == NULL
+	vec3 p;       // closest.point
+};
+
+struct LaneCounters {
+	unsigned int plane, point, edge, box;
+};
+
+__device__ __forceinline__ vec3 xyz(float4 v) { return make3(v.x, v.y, v.z); }
+
+// ---- castRay, brute force (Source.cpp:301-402) ---------------------------------------------
+// `tri` is either the LDS copy or the global planes; the loop index is wave-uniform, so every
+// lane addresses the same float4 (LDS broadcast / scalar load).  `live` masks lanes that hold no
+// ray.  Wave-level early outs replace the reference's per-ray `continue`s: the edge terms are
+// only evaluated when some lane of the wave still needs them, lane results are unaffected.
+template <bool COUNT, typename TriPtr>
+__device__ __forceinline__ Hit cast_ray_brute(TriPtr tri, int stride, int n, vec3 o, vec3 d, int skip,
+                                              bool live, LaneCounters& lc) {
+	Hit h;
+	h.t = 1e9f;
+	h.idx = -1;
+	h.p = make3(0.f, 0.f, 0.f);
+	for (int i = 0; i < n; i++) {
+		const float4 N4 = tri[PL_N * stride + i];
+		const float4 P14 = tri[PL_P1 * stride + i];
+		const vec3 nn = xyz(N4), p1 = xyz(P14);
+		const float t = dot(p1 - o, nn) / dot(d, nn);                       // Source.cpp:383
+		const bool visit = live && (i != skip);                             // Source.cpp:302
+		const bool fwd = visit && !(t < 0.0f);                              // Source.cpp:385
+		const bool cand = fwd && (t < h.t) && (t > RT_EPS_BELOW);           // Source.cpp:391
+		if (COUNT) { lc.plane += visit; lc.point += fwd; lc.edge += cand; }
+		if (__any(cand)) {
+			const vec3 I = make3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);   // Source.cpp:389
+			const float4 E0 = tri[PL_E0 * stride + i];
+			const bool c0 = cand && (dot(nn, cross(xyz(E0), I - p1)) > 0.0f);    // Source.cpp:392
+			if (COUNT) lc.edge += c0;
+			if (__any(c0)) {
+				const float4 P24 = tri[PL_P2 * stride + i];
+				const float4 E1 = tri[PL_E1 * stride + i];
+				const bool c1 = c0 && (dot(nn, cross(xyz(E1), I - xyz(P24))) > 0.0f);   // Source.cpp:393
+				if (COUNT) lc.edge += c1;
+				if (__any(c1)) {
+					const float4 P34 = tri[PL_P3 * stride + i];
+					const float4 E2 = tri[PL_E2 * stride + i];
+					const bool c2 = c1 && (dot(nn, cross(xyz(E2), I - xyz(P34))) > 0.0f);   // Source.cpp:394
+					if (c2) { h.t = t; h.idx = i; h.p = I; }                    // Source.cpp:396
+				}
+			}
+		}
+	}
+	return h;
+}
+
+// ---- pixel <-> work index ------------------------------------------------------------------
+// Work items are numbered tile-major: item g -> tile g/64 (tiles run left to right, then up),
+// pixel g%64 inside the 8x8 tile.  A wave owns `tiles_per_wave` consecutive tiles.
+struct PixelId {
+	int x, ly;      // column, LOCAL row of this shard
+	bool inside;
+};
+
+__device__ __forceinline__ PixelId pixel_of(long long g, int tiles_x, int width, int local_rows, long long n_items) {
+	PixelId p;
+	const long long tile = g >> 6;
+	const int in = (int)(g & 63);
+	const int ty = (int)(tile / tiles_x), tx = (int)(tile - (long long)ty * tiles_x);
+	p.x = tx * 8 + (in & 7);
+	p.ly = ty * 8 + (in >> 3);
+	p.inside = (g < n_items) && (p.x < width) && (p.ly < local_rows);
+	return p;
+}
+
+__device__ __forceinline__ int global_row(int ly, const FrameParams& fp) {
+	// rt_internal.h FrameParams: local row -> tile of this shard -> global tile -> global row
+	const int lt = ly / fp.tile_rows;
+	return (fp.tile_first + lt * fp.tile_stride) * fp.tile_rows + (ly - lt * fp.tile_rows);
+}
+
+// Source.cpp:534-545: u, v in double then rounded; dir = (trans * vec4(u, v, 0.5, 1)).xyz
+__device__ __forceinline__ vec3 primary_dir(int x, int y, const FrameParams& fp) {
+	const float v = (float)(((double)y - (double)fp.height / 2.0) / (double)(float)fp.height);
+	const float u = (float)(((double)x - (double)fp.width / 2.0) / (double)(float)fp.width);
+	const float* m = fp.m;
+	vec3 r;
+	r.x = (m[0] * u + m[4] * v) + (m[8] * 0.5f + m[12] * 1.0f);
+	r.y = (m[1] * u + m[5] * v) + (m[9] * 0.5f + m[13] * 1.0f);
+	r.z = (m[2] * u + m[6] * v) + (m[10] * 0.5f + m[14] * 1.0f);
+	return r;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void flush_counters(unsigned long long* g, const unsigned int (&v)[CTR_N]) {
+	if (!COUNT || g == nullptr) return;
+#pragma unroll
+	for (int k = 0; k < CTR_N; k++) {
+		unsigned int s = v[k];
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+		if ((threadIdx.x & 63) == 0 && s) atomicAdd(&g[k], (unsigned long long)s);
+	}
+}
+
+// ---- the render kernel -----------------------------------------------------------------------
+// ACCEL 0: brute force with the scene in LDS; 1: brute force reading the global planes (scenes
+// too large for LDS); 2: LBVH traversal (rt_lbvh.inl).
+template <int ACCEL, bool COUNT>
+__device__ __forceinline__ Hit trace(const DevScene& sc, const float4* lds_tri, int lds_stride, vec3 o, vec3 d,
+                                     int skip, bool live, LaneCounters& lc);
+
+} // namespace rt
+
+#include "rt_lbvh_trav.inl"
+
+namespace rt {
+
+template <int ACCEL, bool COUNT>
+__device__ __forceinline__ Hit trace(const DevScene& sc, const float4* lds_tri, int lds_stride, vec3 o, vec3 d,
+                                     int skip, bool live, LaneCounters& lc) {
+	if constexpr (ACCEL == 0) {
+		return cast_ray_brute<COUNT>(lds_tri, lds_stride, sc.n_tris, o, d, skip, live, lc);
+	} else if constexpr (ACCEL == 1) {
+		return cast_ray_brute<COUNT>(sc.planes, sc.stride, sc.n_tris, o, d, skip, live, lc);
+	} else {
+		return cast_ray_lbvh<COUNT>(sc, o, d, skip, live, lc);
+	}
+}
+
+// Per-lane attribute fetch by hit index (shininess Source.cpp:570/575, normal :561, colour :489).
+template <int ACCEL>
+__device__ __forceinline__ float4 tri_plane(const DevScene& sc, const float4* lds_tri, int lds_stride, int plane, int idx) {
+	if constexpr (ACCEL == 0) return lds_tri[plane * lds_stride + idx];
+	else return sc.planes[plane * sc.stride + idx];
+}
+
+template <int ACCEL, bool COUNT>
+__global__ void __launch_bounds__(256) render_kernel(DevScene sc, FrameParams fp, int tiles_per_wave) {
+	extern __shared__ float4 s_tri[];
+	const int lds_stride = sc.n_tris;
+	if constexpr (ACCEL == 0) {
+		// stage all planes: consecutive lanes copy consecutive float4 (coalesced 1 KiB per wave op)
+		for (int k = 0; k < PL_COUNT; k++)
+			for (int i = threadIdx.x; i < sc.n_tris; i += blockDim.x)
+				s_tri[k * lds_stride + i] = sc.planes[k * sc.stride + i];
+		__syncthreads();
+	}
+
+	const int tiles_x = (fp.width + 7) >> 3;
+	const int tiles_y = (fp.local_rows + 7) >> 3;
+	const long long n_items = (long long)tiles_x * tiles_y * 64;
+	const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	long long next = wave * tiles_per_wave * 64;                   // wave-uniform cursor
+	long long end = next + (long long)tiles_per_wave * 64;
+	if (end > n_items) end = n_items;
+
+	const vec3 cam = make3(fp.cam[0], fp.cam[1], fp.cam[2]);
+
+	// per-lane ray state
+	int stage = ST_IDLE;
+	vec3 o = cam, d = make3(0.f, 0.f, 0.f);
+	int skip = -1;
+	int out_index = 0;
+	int bounces = 0;
+	float dim = 1.0f;
+	// shading record (what processLighting gets: hit.point, hit.cur) + light cursor + accumulator
+	vec3 hp = make3(0.f, 0.f, 0.f);
+	int hidx = -1;
+	int li = 0;
+	float dist = 0.f;
+	vec3 color = make3(0.f, 0.f, 0.f);
+	bool lit_any = false;
+
+	unsigned int ctr[CTR_N];
+#pragma unroll
+	for (int k = 0; k < CTR_N; k++) ctr[k] = 0;
+	LaneCounters lc = { 0, 0, 0, 0 };
+
+	for (;;) {
+		// ---- regeneration: idle lanes take the next pixels of the wave's tile run ---------------
+		if (next < end) {
+			const bool want = (stage == ST_IDLE);
+			const unsigned long long m = __ballot(want);
+			if (m) {
+				const int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0));
+				const long long g = next + rank;
+				next += __popcll(m);
+				if (want && g < end) {
+					const PixelId px = pixel_of(g, tiles_x, fp.width, fp.local_rows, n_items);
+					if (px.inside) {
+						const int y = global_row(px.ly, fp);
+						out_index = (px.ly * fp.width + px.x) * 3;            // Source.cpp:550 (local rows)
+						d = primary_dir(px.x, y, fp);
+						o = cam;                                             // Source.cpp:545
+						skip = -1;
+						stage = ST_PRIMARY;
+						if (COUNT) ctr[CTR_PRIMARY]++;
+					}
+				}
+			}
+		}
+		const bool live = (stage != ST_IDLE);
+		if (!__any(live)) {
+			if (next >= end) break;
+			continue;
+		}
+
+		// ---- the one closest-hit loop ---------------------------------------------------------
+		const Hit h = trace<ACCEL, COUNT>(sc, s_tri, lds_stride, o, d, skip, live, lc);
+		const bool hit = h.idx >= 0;
+
+		// ---- stage transitions ----------------------------------------------------------------
+		bool shade = false;       // start processLighting on (hp, hidx)
+		bool finish = false;      // write the pixel
+		if (stage == ST_PRIMARY) {
+			if (!hit) {
+				color = make3(0.f, 0.f, 0.f);                                // Source.cpp:623-625
+				dim = 1.0f;
+				finish = true;
+			} else {
+				if (COUNT) ctr[CTR_PXHIT]++;
+				const float4 N4 = tri_plane<ACCEL>(sc, s_tri, lds_stride, PL_N, h.idx);
+				if (N4.w > 0.5f) {                                           // Source.cpp:570
+					const vec3 normal = face_normal(d, xyz(N4));             // Source.cpp:561
+					d = normalize(reflect(d, normal));                       // Source.cpp:572
+					o = h.p;
+					skip = h.idx;                                            // Source.cpp:573
+					bounces = 0;
+					stage = ST_BOUNCE;
+					if (COUNT) { ctr[CTR_PXMIRROR]++; ctr[CTR_BOUNCE]++; }
+				} else {
+					hp = h.p; hidx = h.idx; dim = 1.0f;                      // Source.cpp:597
+					shade = true;
+				}
+			}
+		} else if (stage == ST_BOUNCE) {
+			float shin = 0.f;
+			float4 N4 = make_float4(0.f, 0.f, 0.f, 0.f);
+			if (hit) { N4 = tri_plane<ACCEL>(sc, s_tri, lds_stride, PL_N, h.idx); shin = N4.w; }
+			if (hit && bounces < fp.max_bounces && shin > 0.5f) {            // Source.cpp:575
+				const vec3 normal = face_normal(d, xyz(N4));                 // Source.cpp:576
+				d = normalize(reflect(d, normal));                           // Source.cpp:577
+				o = h.p;
+				skip = h.idx;                                                // Source.cpp:578
+				bounces++;
+				if (COUNT) ctr[CTR_BOUNCE]++;
+			} else if (hit) {                                                // Source.cpp:582
+				hp = h.p; hidx = h.idx;
+				dim = (float)(bounces * 1);                                  // Source.cpp:585
+				shade = true;
+			} else {
+				color = make3(0.f, 0.f, 0.f);                                // Source.cpp:590
+				dim = 1.0f;
+				finish = true;
+			}
+		} else if (stage == ST_SHADOW) {
+			if (!hit || h.t > dist) {                                        // Source.cpp:476
+				const float4 L = sc.lights[li];
+				const float f = 1.0f / (dist * dist) * L.w;                  // Source.cpp:488
+				const float modify = (float)((double)f / 255.0 / (double)255.0f);
+				const float cr = tri_plane<ACCEL>(sc, s_tri, lds_stride, PL_P1, hidx).w;
+				const float cg = tri_plane<ACCEL>(sc, s_tri, lds_stride, PL_P2, hidx).w;
+				const float cb = tri_plane<ACCEL>(sc, s_tri, lds_stride, PL_P3, hidx).w;
+				color.x = color.x + modify * cr;                             // Source.cpp:489
+				color.y = color.y + modify * cg;
+				color.z = color.z + modify * cb;
+				lit_any = true;
+			}
+			li++;
+			if (li >= sc.n_lights) finish = true;
+		}
+
+		if (shade) {
+			color = make3(0.f, 0.f, 0.f);                                    // Source.cpp:462
+			li = 0;
+			lit_any = false;
+			stage = ST_SHADOW;
+			if (sc.n_lights <= 0) finish = true;
+		}
+		if (stage == ST_SHADOW && !finish) {
+			// next shadow ray (Source.cpp:470-474)
+			const float4 L = sc.lights[li];
+			const vec3 ray = make3(L.x - hp.x, L.y - hp.y, L.z - hp.z);
+			const float dd = dot(ray, ray);
+			const float s = sqrtf(dd);
+			const float inv = 1.0f / s;                                      // glm::normalize: v * inversesqrt(dot(v,v))
+			d = ray * inv;
+			dist = s;                                                        // magnitude(ray), Source.cpp:26-28
+			o = hp;
+			skip = hidx;
+			if (COUNT) ctr[CTR_SHADOW]++;
+		}
+		if (finish) {
+			if (COUNT && lit_any) ctr[CTR_PXLIT]++;
+			vec3 c = color;
+			c.x = c.x * dim; c.y = c.y * dim; c.z = c.z * dim;               // Source.cpp:586; dim == 1 (exact) on the matte and miss paths
+			if (c.x > 1.0f) c.x = 1.0f;                                      // Source.cpp:602-610
+			if (c.y > 1.0f) c.y = 1.0f;
+			if (c.z > 1.0f) c.z = 1.0f;
+			float* out = fp.out + out_index;
+			out[0] = c.x; out[1] = c.y; out[2] = c.z;                        // Source.cpp:612-614
+			stage = ST_IDLE;
+			lit_any = false;
+		}
+	}
+
+	if (COUNT) {
+		ctr[CTR_PLANE] = lc.plane; ctr[CTR_POINT] = lc.point; ctr[CTR_EDGE] = lc.edge; ctr[CTR_BOX] = lc.box;
+		flush_counters<COUNT>(fp.counters, ctr);
+	}
+}
+
+// ---- castRay for a batch of rays (tests, tools) ----------------------------------------------
+template <int ACCEL>
+__global__ void __launch_bounds__(256) cast_rays_kernel(DevScene sc, int n, const float* __restrict__ rays7, float* __restrict__ out6) {
+	extern __shared__ float4 s_tri[];
+	const int lds_stride = sc.n_tris;
+	if constexpr (ACCEL == 0) {
+		for (int k = 0; k < PL_COUNT; k++)
+			for (int i = threadIdx.x; i < sc.n_tris; i += blockDim.x)
+				s_tri[k * lds_stride + i] = sc.planes[k * sc.stride + i];
+		__syncthreads();
+	}
+	const int r = blockIdx.x * blockDim.x + threadIdx.x;
+	const bool live = r < n;
+	vec3 o = make3(0.f, 0.f, 0.f), d = make3(0.f, 0.f, 1.f);
+	int skip = -1;
+	if (live) {
+		const float* q = rays7 + (size_t)r * 7;
+		o = make3(q[0], q[1], q[2]);
+		d = make3(q[3], q[4], q[5]);
+		const float sk = q[6];
+		skip = (sk >= 0.0f && sk < (float)sc.n_tris) ? (int)sk : -1;
+	}
+	LaneCounters lc = { 0, 0, 0, 0 };
+	const Hit h = trace<ACCEL, false>(sc, s_tri, lds_stride, o, d, skip, live, lc);
+	if (live) {
+		float* w = out6 + (size_t)r * 6;
+		w[0] = h.idx >= 0 ? 1.0f : 0.0f;
+		w[1] = (float)h.idx;
+		w[2] = h.t;
+		w[3] = h.p.x; w[4] = h.p.y; w[5] = h.p.z;
+	}
+}
+
+// ---- host launchers ----------------------------------------------------------------------------
+
+DevScene dev_scene(const rt_scene* s, const DeviceState& d) {
+	DevScene sc;
+	sc.planes = (const float4*)d.planes;
+	sc.lights = (const float4*)d.lights;
+	sc.n_tris = (int)(s->tris.size() / RT_TRI_FLOATS);
+	sc.stride = d.stride;
+	sc.n_lights = (int)(s->lights.size() / 4);
+	sc.pad = 0;
+	sc.bvh_nodes = (const float4*)d.bvh_nodes;
+	sc.bvh_prim = (const int*)d.bvh_prim;
+	sc.bvh_root = d.bvh_root;
+	sc.pad2 = 0;
+	return sc;
+}
+
+static int pick_tiles_per_wave(long long tiles) {
+	// Enough waves to fill 256 CUs x 4 SIMDs several times over, long enough runs for the
+	// regeneration to have something to refill with.
+	const long long target_waves = 1024 * 8;
+	long long tpw = (tiles + target_waves - 1) / target_waves;
+	if (tpw < 1) tpw = 1;
+	if (tpw > 64) tpw = 64;
+	return (int)tpw;
+}
+
+int launch_render(const DevScene& sc, const FrameParams& fp, int accel, int render_flags, bool count, hipStream_t stream) {
+	(void)render_flags;
+	if (fp.width <= 0 || fp.local_rows <= 0) return RT_OK;
+	const long long tiles = (long long)((fp.width + 7) / 8) * ((fp.local_rows + 7) / 8);
+	int tpw = fp.tiles_per_wave > 0 ? fp.tiles_per_wave : pick_tiles_per_wave(tiles);
+	const long long waves = (tiles + tpw - 1) / tpw;
+	const long long blocks = (waves + 3) / 4;
+	if (blocks > 0x7fffffffLL) { set_error("rt_render: frame too large (%lld workgroups)", blocks); return RT_ERR_LIMIT; }
+	const dim3 grid((unsigned)blocks), block(256);
+	if (accel == RT_ACCEL_LBVH) {
+		if (count) hipLaunchKernelGGL((render_kernel<2, true>), grid, block, 0, stream, sc, fp, tpw);
+		else hipLaunchKernelGGL((render_kernel<2, false>), grid, block, 0, stream, sc, fp, tpw);
+	} else if (sc.n_tris <= RT_LDS_MAX_TRIS) {
+		const size_t lds = (size_t)PL_COUNT * sc.n_tris * sizeof(float4);
+		if (count) hipLaunchKernelGGL((render_kernel<0, true>), grid, block, lds, stream, sc, fp, tpw);
+		else hipLaunchKernelGGL((render_kernel<0, false>), grid, block, lds, stream, sc, fp, tpw);
+	} else {
+		if (count) hipLaunchKernelGGL((render_kernel<1, true>), grid, block, 0, stream, sc, fp, tpw);
+		else hipLaunchKernelGGL((render_kernel<1, false>), grid, block, 0, stream, sc, fp, tpw);
+	}
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) return hip_fail(e, "render kernel launch");
+	return RT_OK;
+}
+
+int launch_cast_rays(const DevScene& sc, int accel, int n, const float* d_rays7, float* d_out6, hipStream_t stream) {
+	if (n <= 0) return RT_OK;
+	const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+	if (accel == RT_ACCEL_LBVH) {
+		hipLaunchKernelGGL((cast_rays_kernel<2>), grid, block, 0, stream, sc, n, d_rays7, d_out6);
+	} else if (sc.n_tris <= RT_LDS_MAX_TRIS) {
+		const size_t lds = (size_t)PL_COUNT * sc.n_tris * sizeof(float4);
+		hipLaunchKernelGGL((cast_rays_kernel<0>), grid, block, lds, stream, sc, n, d_rays7, d_out6);
+	} else {
+		hipLaunchKernelGGL((cast_rays_kernel<1>), grid, block, 0, stream, sc, n, d_rays7, d_out6);
+	}
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) return hip_fail(e, "cast_rays kernel launch");
+	return RT_OK;
+}
+
+} // namespace rt

@@ -1,0 +1,268 @@
+// rt_scene.cpp — host-side scene construction: the reference's start-up arithmetic
+// (Triangle ctor Source.cpp:45-59, addTriangle Source.cpp:410-439, trans Source.cpp:1145-1147,
+// loadModel Source.cpp:631-657) and the flatten-to-SoA step that precedes the upload.
+//
+// Compiled with -ffp-contract=off: these records are the inputs of every later comparison, so
+// they must be the bits the reference's own constructors produce.  sinf/cosf come from the host
+// libm exactly as they do for the reference (glm::rotate -> std::cos / std::sin).
+#include "rt_internal.h"
+
+#include <cerrno>
+#include <cstdio>
+#include <cstring>
+
+namespace rt {
+
+namespace {
+
+mat4 identity() {
+	mat4 m;
+	m.c[0] = make4(1, 0, 0, 0);
+	m.c[1] = make4(0, 1, 0, 0);
+	m.c[2] = make4(0, 0, 1, 0);
+	m.c[3] = make4(0, 0, 0, 1);
+	return m;
+}
+
+// glm::radians: degrees * 0.01745329251994329576923690768489 (as float)
+float radians(float deg) { return deg * 0.01745329251994329576923690768489f; }
+
+// glm/ext/matrix_transform.inl:10-15
+mat4 translate(const mat4& m, vec3 v) {
+	mat4 r = m;
+	r.c[3] = m.c[0] * v.x + m.c[1] * v.y + m.c[2] * v.z + m.c[3];
+	return r;
+}
+
+// glm/ext/matrix_transform.inl:18-46
+mat4 rotate(const mat4& m, float angle, vec3 v) {
+	const float a = angle;
+	const float c = cosf(a);
+	const float s = sinf(a);
+	vec3 axis = normalize(v);
+	vec3 temp = axis * (1.0f - c);
+	float R[3][3];
+	R[0][0] = c + temp.x * axis.x;
+	R[0][1] = temp.x * axis.y + s * axis.z;
+	R[0][2] = temp.x * axis.z - s * axis.y;
+	R[1][0] = temp.y * axis.x - s * axis.z;
+	R[1][1] = c + temp.y * axis.y;
+	R[1][2] = temp.y * axis.z + s * axis.x;
+	R[2][0] = temp.z * axis.x + s * axis.y;
+	R[2][1] = temp.z * axis.y - s * axis.x;
+	R[2][2] = c + temp.z * axis.z;
+	mat4 r;
+	for (int i = 0; i < 3; i++) r.c[i] = m.c[0] * R[i][0] + m.c[1] * R[i][1] + m.c[2] * R[i][2];
+	r.c[3] = m.c[3];
+	return r;
+}
+
+// glm/ext/matrix_transform.inl:78-86
+mat4 scale(const mat4& m, vec3 v) {
+	mat4 r;
+	r.c[0] = m.c[0] * v.x;
+	r.c[1] = m.c[1] * v.y;
+	r.c[2] = m.c[2] * v.z;
+	r.c[3] = m.c[3];
+	return r;
+}
+
+// glm/detail/type_mat4x4.inl:630-648
+mat4 matmul(const mat4& a, const mat4& b) {
+	mat4 r;
+	for (int i = 0; i < 4; i++) {
+		vec4 bc = b.c[i];
+		r.c[i] = a.c[0] * bc.x + a.c[1] * bc.y + a.c[2] * bc.z + a.c[3] * bc.w;
+	}
+	return r;
+}
+
+void put3(float* o, vec3 v) { o[0] = v.x; o[1] = v.y; o[2] = v.z; }
+
+} // namespace
+
+void triangle_record(vec3 p1, vec3 p2, vec3 p3, vec3 color, float shin, float* o) {
+	// Source.cpp:45-59
+	vec3 n = normalize(cross(p1 - p2, p1 - p3));
+	put3(o + 0, p1);           // p
+	put3(o + 3, n);
+	put3(o + 6, p1);
+	put3(o + 9, p2);
+	put3(o + 12, p3);
+	put3(o + 15, p2 - p1);     // edge0
+	put3(o + 18, p3 - p2);     // edge1
+	put3(o + 21, p1 - p3);     // edge2
+	put3(o + 24, color);
+	o[27] = shin;
+}
+
+void quad_half_record(const float T[3], const float Rdeg[3], const float S[3], const float color[3],
+                      float shin, float* out28) {
+	// Source.cpp:410-439: base triangle, mod = translate * rotatex * rotatey * rotatez * scale
+	vec4 p1 = make4(-1, -1, 0, 1), p2 = make4(-1, 1, 0, 1), p3 = make4(1, -1, 0, 1);
+	const mat4 I = identity();
+	mat4 t = translate(I, make3(T[0], T[1], T[2]));
+	mat4 rx = rotate(I, radians(Rdeg[0]), make3(1, 0, 0));
+	mat4 ry = rotate(I, radians(Rdeg[1]), make3(0, 1, 0));
+	mat4 rz = rotate(I, radians(Rdeg[2]), make3(0, 0, 1));
+	mat4 sc = scale(I, make3(S[0], S[1], S[2]));
+	mat4 mod = matmul(matmul(matmul(matmul(t, rx), ry), rz), sc);
+	p1 = mul(mod, p1);
+	p2 = mul(mod, p2);
+	p3 = mul(mod, p3);
+	triangle_record(make3(p1.x, p1.y, p1.z), make3(p2.x, p2.y, p2.z), make3(p3.x, p3.y, p3.z),
+	                make3(color[0], color[1], color[2]), shin, out28);
+}
+
+void camera_trans(const float rot_deg[3], float out16[16]) {
+	// Source.cpp:1145-1147
+	mat4 t = identity();
+	t = rotate(t, radians(rot_deg[0]), make3(0.0f, 1.0f, 0.0f));
+	t = rotate(t, radians(-rot_deg[1]), make3(1.0f, 0.0f, 0.0f));
+	memcpy(out16, &t, sizeof(float) * 16);
+}
+
+void flatten_planes(const std::vector<float>& tris, int stride, std::vector<float>& out) {
+	const int n = (int)(tris.size() / RT_TRI_FLOATS);
+	out.assign((size_t)PL_COUNT * stride * 4, 0.0f);
+	auto plane = [&](int k, int i) { return out.data() + ((size_t)k * stride + i) * 4; };
+	for (int i = 0; i < n; i++) {
+		const float* t = tris.data() + (size_t)i * RT_TRI_FLOATS;
+		const float* nrm = t + 3; const float* p1 = t + 6; const float* p2 = t + 9; const float* p3 = t + 12;
+		const float* e0 = t + 15; const float* e1 = t + 18; const float* e2 = t + 21; const float* col = t + 24;
+		float* q;
+		q = plane(PL_N, i);  q[0] = nrm[0]; q[1] = nrm[1]; q[2] = nrm[2]; q[3] = t[27];
+		q = plane(PL_P1, i); q[0] = p1[0]; q[1] = p1[1]; q[2] = p1[2]; q[3] = col[0];
+		q = plane(PL_P2, i); q[0] = p2[0]; q[1] = p2[1]; q[2] = p2[2]; q[3] = col[1];
+		q = plane(PL_P3, i); q[0] = p3[0]; q[1] = p3[1]; q[2] = p3[2]; q[3] = col[2];
+		q = plane(PL_E0, i); q[0] = e0[0]; q[1] = e0[1]; q[2] = e0[2];
+		q = plane(PL_E1, i); q[0] = e1[0]; q[1] = e1[1]; q[2] = e1[2];
+		q = plane(PL_E2, i); q[0] = e2[0]; q[1] = e2[1]; q[2] = e2[2];
+	}
+}
+
+} // namespace rt
+
+using namespace rt;
+
+extern "C" {
+
+rt_scene* rt_scene_create(void) {
+	try { return new rt_scene(); } catch (...) { set_error("rt_scene_create: out of memory"); return nullptr; }
+}
+
+int rt_scene_clear(rt_scene* s) {
+	if (!s) { set_error("rt_scene_clear: NULL scene"); return RT_ERR_INVALID; }
+	s->tris.clear();
+	s->lights.clear();
+	s->generation++;
+	for (auto& kv : s->dev) kv.second.valid = false;
+	return RT_OK;
+}
+
+static void touched(rt_scene* s) {
+	s->generation++;
+	for (auto& kv : s->dev) kv.second.valid = false;
+}
+
+int rt_scene_add_triangle(rt_scene* s, const float p1[3], const float p2[3], const float p3[3],
+                          const float color[3], float shininess) {
+	if (!s || !p1 || !p2 || !p3 || !color) { set_error("rt_scene_add_triangle: NULL argument"); return RT_ERR_INVALID; }
+	try {
+		s->tris.resize(s->tris.size() + RT_TRI_FLOATS);
+	} catch (...) { set_error("rt_scene_add_triangle: out of memory"); return RT_ERR_NOMEM; }
+	triangle_record(make3(p1[0], p1[1], p1[2]), make3(p2[0], p2[1], p2[2]), make3(p3[0], p3[1], p3[2]),
+	                make3(color[0], color[1], color[2]), shininess, s->tris.data() + s->tris.size() - RT_TRI_FLOATS);
+	touched(s);
+	return RT_OK;
+}
+
+int rt_scene_add_triangles(rt_scene* s, int n, const float* p1, const float* p2, const float* p3,
+                           const float* color, const float* shininess) {
+	if (!s || n < 0 || (n > 0 && (!p1 || !p2 || !p3 || !color || !shininess))) {
+		set_error("rt_scene_add_triangles: NULL argument or negative count");
+		return RT_ERR_INVALID;
+	}
+	size_t base = s->tris.size();
+	try {
+		s->tris.resize(base + (size_t)n * RT_TRI_FLOATS);
+	} catch (...) { set_error("rt_scene_add_triangles: out of memory"); return RT_ERR_NOMEM; }
+	for (int i = 0; i < n; i++) {
+		const float *a = p1 + 3 * i, *b = p2 + 3 * i, *c = p3 + 3 * i, *col = color + 3 * i;
+		triangle_record(make3(a[0], a[1], a[2]), make3(b[0], b[1], b[2]), make3(c[0], c[1], c[2]),
+		                make3(col[0], col[1], col[2]), shininess[i], s->tris.data() + base + (size_t)i * RT_TRI_FLOATS);
+	}
+	touched(s);
+	return RT_OK;
+}
+
+int rt_scene_add_quad_half(rt_scene* s, const float translate[3], const float rotate_deg[3],
+                           const float scale[3], const float color[3], float shininess) {
+	if (!s || !translate || !rotate_deg || !scale || !color) { set_error("rt_scene_add_quad_half: NULL argument"); return RT_ERR_INVALID; }
+	try {
+		s->tris.resize(s->tris.size() + RT_TRI_FLOATS);
+	} catch (...) { set_error("rt_scene_add_quad_half: out of memory"); return RT_ERR_NOMEM; }
+	quad_half_record(translate, rotate_deg, scale, color, shininess, s->tris.data() + s->tris.size() - RT_TRI_FLOATS);
+	touched(s);
+	return RT_OK;
+}
+
+int rt_scene_add_light(rt_scene* s, const float position[3], float intensity) {
+	if (!s || !position) { set_error("rt_scene_add_light: NULL argument"); return RT_ERR_INVALID; }
+	try {
+		s->lights.insert(s->lights.end(), { position[0], position[1], position[2], intensity });
+	} catch (...) { set_error("rt_scene_add_light: out of memory"); return RT_ERR_NOMEM; }
+	touched(s);
+	return RT_OK;
+}
+
+int rt_scene_load_rto(rt_scene* s, const char* path) {
+	// Source.cpp:631-657 loadModel — same fscanf grammar; the reference's exit(1) paths become
+	// error codes.  Like the reference, a short match (ret > 0 but < 12) still calls addTriangle
+	// with whatever was parsed; unlike it, the unparsed fields are zero rather than uninitialised.
+	if (!s || !path) { set_error("rt_scene_load_rto: NULL argument"); return RT_ERR_INVALID; }
+	FILE* file = fopen(path, "rb");
+	if (file == NULL) {
+		set_error("rt_scene_load_rto: %s: %s", path, strerror(errno));   // reference: "File not found"
+		return RT_ERR_IO;
+	}
+	int added = 0;
+	while (true) {
+		float a1 = 0, a2 = 0, a3 = 0, b1 = 0, b2 = 0, b3 = 0, c1 = 0, c2 = 0, c3 = 0;
+		int d1 = 0, d2 = 0, d3 = 0;
+		int ret = fscanf(file, "(%f, %f, %f), (%f, %f, %f), (%f, %f, %f), (%d, %d, %d); ",
+		                 &a1, &a2, &a3, &b1, &b2, &b3, &c1, &c2, &c3, &d1, &d2, &d3);
+		if (ret == -1) break;
+		if (ret == 0) {
+			fclose(file);
+			set_error("rt_scene_load_rto: %s: malformed record after %d triangles", path, added);   // reference: "Error with loading a model"
+			return RT_ERR_IO;
+		}
+		const float T[3] = { a1, a2, a3 }, R[3] = { b1, b2, b3 }, S[3] = { c1, c2, c3 };
+		const float col[3] = { (float)d1, (float)d2, (float)d3 };
+		int rc = rt_scene_add_quad_half(s, T, R, S, col, 0);
+		if (rc != RT_OK) { fclose(file); return rc; }
+		added++;
+	}
+	fclose(file);
+	return added;
+}
+
+int rt_scene_triangle_count(const rt_scene* s) { return s ? (int)(s->tris.size() / RT_TRI_FLOATS) : RT_ERR_INVALID; }
+int rt_scene_light_count(const rt_scene* s) { return s ? (int)(s->lights.size() / 4) : RT_ERR_INVALID; }
+
+int rt_scene_get_triangles(const rt_scene* s, float* out28, int capacity) {
+	if (!s || (capacity > 0 && !out28) || capacity < 0) { set_error("rt_scene_get_triangles: bad argument"); return RT_ERR_INVALID; }
+	int n = (int)(s->tris.size() / RT_TRI_FLOATS);
+	if (n > capacity) n = capacity;
+	if (n > 0) memcpy(out28, s->tris.data(), (size_t)n * RT_TRI_FLOATS * sizeof(float));
+	return n;
+}
+
+int rt_camera_trans(const float rot_deg[3], float out_trans16[16]) {
+	if (!rot_deg || !out_trans16) { set_error("rt_camera_trans: NULL argument"); return RT_ERR_INVALID; }
+	camera_trans(rot_deg, out_trans16);
+	return RT_OK;
+}
+
+} // extern "C"
