@@ -68,6 +68,26 @@ _fp = C.POINTER(C.c_float)
 _lib = None
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """One HIP runtime per process.  PyTorch wheels bundle their own libamdhip64.so (same SONAME
+    as /opt/rocm's); whichever copy is loaded first must serve both torch and librt355.so, or the
+    second copy finds "no HIP GPUs".  If torch is installed but not imported yet, load ITS copy
+    first so that librt355.so's DT_NEEDED entry binds to it and a later `import torch` re-uses it."""
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """Load librt355.so.  Raises (never falls back) when it has not been built."""
     global _lib
@@ -76,6 +96,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s is missing: build it with `make -C raytracing_amd/csrc` "
                           "(or __graft_entry__.build()); there is no fallback path" % LIB_PATH)
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     vp, ci, cf = C.c_void_p, C.c_int, C.c_float
     L.rt_scene_create.restype = vp

@@ -1,0 +1,189 @@
+// rt_headless.cpp — headless stand-in for the reference's main() (Source.cpp:803-1314) without the
+// GL viewer: builds a scene through the C ABI exactly as main() does through addTriangle /
+// lights.push_back (Source.cpp:815-851, 880), renders frames with rt_render (which replaces the
+// getPixelData loop, Source.cpp:1248-1264), prints the reference's per-frame "ms / FPS" line
+// (Source.cpp:1297-1301) and dumps the framebuffer for comparison:
+//
+//   Image.txt / .ppm (P3)  "P3\nW H\n255\n" then one "R G B" triple per line — the layout of the
+//                          stale RayTracing/src/Image.txt / Image.ppm the reference tree carries
+//   .ppm (P6)              binary, same pixels
+//   .f32                   the raw float data[h*w*3] (row 0 = bottom, Source.cpp:550)
+//
+// Image files are written top row first (data row h-1 first) so that a viewer shows what the GL
+// quad shows.  8-bit values use the GL unorm rule q = (int)(c*255.0f + 0.5f).
+//
+//   rt_headless [--scene stock|FILE] [--size W H] [--depth D] [--camera px py pz rx ry rz]
+//               [--frames N] [--fast] [--lbvh|--brute] [--device K]
+//               [--txt Image.txt] [--ppm out.ppm] [--raw out.f32] [--rto model.rto]
+//
+// FILE uses the text format of oracle/SCENE_FORMAT.md.  No CPU rendering happens here.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rt355.h"
+
+namespace {
+
+struct Options {
+	std::string scene = "stock";
+	int width = 800, height = 800;     // Source.cpp:887-888
+	bool size_set = false;
+	int depth = 1;                     // Source.cpp:567
+	bool depth_set = false;
+	float cam[6] = { -5, 5, 5, 135, -45, 0 };   // Source.cpp:810
+	bool cam_set = false;
+	int frames = 1;
+	int mode = RT_RENDER_STRICT;
+	int accel = RT_ACCEL_AUTO;
+	int device = 0;
+	std::string txt, ppm, raw, rto;
+};
+
+int fail(const char* what) {
+	fprintf(stderr, "rt_headless: %s: %s\n", what, rt_last_error());
+	return 1;
+}
+
+// Source.cpp:815-851, 880: the stock scene, call for call.
+int build_stock(rt_scene* s) {
+	struct Wall { float t[3]; float r[3]; float col[3]; };
+	const Wall room[6] = {
+		{ { 0, 0, 10 }, { 0, 0, 0 }, { 255, 0, 0 } },   { { 0, 0, -10 }, { 0, 0, 0 }, { 255, 0, 128 } },
+		{ { 10, 0, 0 }, { 0, 90, 0 }, { 0, 255, 0 } },  { { -10, 0, 0 }, { 0, 90, 0 }, { 0, 255, 128 } },
+		{ { 0, -10, 0 }, { 90, 0, 0 }, { 0, 0, 255 } }, { { 0, 10, 0 }, { 90, 0, 0 }, { 255, 0, 255 } },
+	};
+	const Wall cube[6] = {
+		{ { 0, 0, 1 }, { 0, 0, 0 }, { 255, 255, 255 } },  { { 0, 0, -1 }, { 0, 0, 0 }, { 255, 255, 255 } },
+		{ { 1, 0, 0 }, { 0, 90, 0 }, { 255, 255, 255 } }, { { -1, 0, 0 }, { 0, 90, 0 }, { 255, 255, 255 } },
+		{ { 0, -1, 0 }, { 90, 0, 0 }, { 255, 255, 255 } }, { { 0, 1, 0 }, { 90, 0, 0 }, { 255, 255, 255 } },
+	};
+	for (int pass = 0; pass < 2; pass++) {
+		const Wall* w = pass ? cube : room;
+		const float sc = pass ? 1.0f : 10.0f;
+		const float S[3] = { sc, sc, sc };
+		for (int i = 0; i < 6; i++) {
+			float r2[3] = { w[i].r[0], w[i].r[1], w[i].r[2] + 180.0f };
+			if (rt_scene_add_quad_half(s, w[i].t, w[i].r, S, w[i].col, 0) != RT_OK) return -1;
+			if (rt_scene_add_quad_half(s, w[i].t, r2, S, w[i].col, 0) != RT_OK) return -1;
+		}
+	}
+	const float lp[3] = { 0, 8, 0 };
+	return rt_scene_add_light(s, lp, 4096);
+}
+
+int build_from_file(rt_scene* s, Options& o) {
+	FILE* f = fopen(o.scene.c_str(), "r");
+	if (!f) { fprintf(stderr, "rt_headless: cannot open %s\n", o.scene.c_str()); return -1; }
+	char line[2048];
+	int lineno = 0;
+	while (fgets(line, sizeof line, f)) {
+		lineno++;
+		char* p = line;
+		while (*p == ' ' || *p == '\t') p++;
+		if (*p == '#' || *p == '\n' || *p == 0) continue;
+		char kw[32];
+		int off = 0;
+		if (sscanf(p, "%31s%n", kw, &off) != 1) continue;
+		p += off;
+		float v[16];
+		int n = 0;
+		while (n < 16) {
+			char* end;
+			float x = strtof(p, &end);
+			if (end == p) break;
+			v[n++] = x;
+			p = end;
+		}
+		int rc = RT_OK;
+		if (!strcmp(kw, "quadhalf") && n == 13) rc = rt_scene_add_quad_half(s, v, v + 3, v + 6, v + 9, v[12]);
+		else if (!strcmp(kw, "tri") && n == 13) rc = rt_scene_add_triangle(s, v, v + 3, v + 6, v + 9, v[12]);
+		else if (!strcmp(kw, "light") && n == 4) rc = rt_scene_add_light(s, v, v[3]);
+		else if (!strcmp(kw, "camera") && n == 6) { if (!o.cam_set) memcpy(o.cam, v, sizeof o.cam); }
+		else if (!strcmp(kw, "size") && n == 2) { if (!o.size_set) { o.width = (int)v[0]; o.height = (int)v[1]; } }
+		else if (!strcmp(kw, "depth") && n == 1) { if (!o.depth_set) o.depth = (int)v[0]; }
+		else { fprintf(stderr, "rt_headless: %s:%d: bad line\n", o.scene.c_str(), lineno); fclose(f); return -1; }
+		if (rc != RT_OK) { fclose(f); return -1; }
+	}
+	fclose(f);
+	return 0;
+}
+
+unsigned char q8(float c) {
+	if (!(c > 0.0f)) return 0;
+	if (c > 1.0f) c = 1.0f;
+	return (unsigned char)(int)(c * 255.0f + 0.5f);
+}
+
+bool write_image(const std::string& path, const std::vector<float>& data, int w, int h, bool text) {
+	FILE* f = fopen(path.c_str(), text ? "w" : "wb");
+	if (!f) return false;
+	fprintf(f, "%s\n%d %d\n255\n", text ? "P3" : "P6", w, h);
+	for (int y = h - 1; y >= 0; y--)
+		for (int x = 0; x < w; x++) {
+			const float* p = &data[((size_t)y * w + x) * 3];
+			unsigned char rgb[3] = { q8(p[0]), q8(p[1]), q8(p[2]) };
+			if (text) fprintf(f, "%d %d %d\n", rgb[0], rgb[1], rgb[2]);
+			else fwrite(rgb, 1, 3, f);
+		}
+	return fclose(f) == 0;
+}
+
+} // namespace
+
+int main(int argc, char** argv) {
+	Options o;
+	for (int i = 1; i < argc; i++) {
+		std::string a = argv[i];
+		auto need = [&](int k) { if (i + k >= argc) { fprintf(stderr, "rt_headless: %s needs %d value(s)\n", a.c_str(), k); exit(2); } };
+		if (a == "--scene") { need(1); o.scene = argv[++i]; }
+		else if (a == "--size") { need(2); o.width = atoi(argv[++i]); o.height = atoi(argv[++i]); o.size_set = true; }
+		else if (a == "--depth") { need(1); o.depth = atoi(argv[++i]); o.depth_set = true; }
+		else if (a == "--camera") { need(6); for (int k = 0; k < 6; k++) o.cam[k] = strtof(argv[++i], nullptr); o.cam_set = true; }
+		else if (a == "--frames") { need(1); o.frames = atoi(argv[++i]); }
+		else if (a == "--fast") o.mode = RT_RENDER_FAST;
+		else if (a == "--lbvh") o.accel = RT_ACCEL_LBVH;
+		else if (a == "--brute") o.accel = RT_ACCEL_BRUTE;
+		else if (a == "--device") { need(1); o.device = atoi(argv[++i]); }
+		else if (a == "--txt") { need(1); o.txt = argv[++i]; }
+		else if (a == "--ppm") { need(1); o.ppm = argv[++i]; }
+		else if (a == "--raw") { need(1); o.raw = argv[++i]; }
+		else if (a == "--rto") { need(1); o.rto = argv[++i]; }
+		else { fprintf(stderr, "rt_headless: unknown option %s (see the header of rt_headless.cpp)\n", a.c_str()); return 2; }
+	}
+	rt_scene* s = rt_scene_create();
+	if (!s) return fail("rt_scene_create");
+	int rc = (o.scene == "stock") ? build_stock(s) : build_from_file(s, o);
+	if (rc != 0) { fail("scene"); rt_scene_destroy(s); return 1; }
+	if (!o.rto.empty() && rt_scene_load_rto(s, o.rto.c_str()) < 0) { fail("loadModel"); rt_scene_destroy(s); return 1; }
+	if (rt_scene_commit(s, o.device, o.accel) != RT_OK) { fail("rt_scene_commit"); rt_scene_destroy(s); return 1; }
+
+	float trans[16];
+	rt_camera_trans(o.cam + 3, trans);                                  // Source.cpp:1145-1147
+	std::vector<float> data((size_t)o.width * o.height * 3);            // Source.cpp:1035
+	float build_ms = 0;
+	rt_scene_build_ms(s, o.device, &build_ms);
+	printf("triangles %d lights %d accel %s build %.3f ms\n", rt_scene_triangle_count(s), rt_scene_light_count(s),
+	       rt_scene_accel(s, o.device) == RT_ACCEL_LBVH ? "lbvh" : "brute", build_ms);
+	for (int f = 0; f < o.frames; f++) {
+		auto t0 = std::chrono::steady_clock::now();                     // Source.cpp:1129
+		if (rt_render(s, o.cam, trans, o.width, o.height, o.depth, o.mode, data.data()) != RT_OK) { fail("rt_render"); rt_scene_destroy(s); return 1; }
+		auto t1 = std::chrono::steady_clock::now();
+		double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+		printf("%f ms %f FPS\n", ms, 1000.0 / ms);                      // Source.cpp:1301
+	}
+	bool ok = true;
+	if (!o.txt.empty()) ok = write_image(o.txt, data, o.width, o.height, true) && ok;
+	if (!o.ppm.empty()) ok = write_image(o.ppm, data, o.width, o.height, false) && ok;
+	if (!o.raw.empty()) {
+		FILE* f = fopen(o.raw.c_str(), "wb");
+		ok = f && fwrite(data.data(), sizeof(float), data.size(), f) == data.size() && ok;
+		if (f) fclose(f);
+	}
+	rt_scene_destroy(s);
+	if (!ok) { fprintf(stderr, "rt_headless: could not write an output file\n"); return 1; }
+	return 0;
+}
