@@ -177,7 +177,21 @@ def main():
         fb = torch.empty(H * W * 3, dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
+    # pre-marshalled arguments: the timed loop is then one ctypes call per frame
+    import ctypes as C
+    L = api.lib()
+    fptr = C.POINTER(C.c_float)
+    cam_c = [np.ascontiguousarray(p, dtype=np.float32) for p, _ in poses]
+    cam_p = [a.ctypes.data_as(fptr) for a in cam_c]
+    trans_p = [a.ctypes.data_as(fptr) for a in trans]
+    fb_ptr, stream_p, handle = C.c_void_p(fb.data_ptr()), C.c_void_p(stream), scene._h
+
     def step(f):
+        if not tile_mode:
+            rc = L.rt_render_device(handle, dev, cam_p[f], trans_p[f], W, H, D, mode, fb_ptr, stream_p)
+            if rc != 0:
+                raise api.RtError(rc, L.rt_last_error().decode())
+            return
         if tile_mode:
             scene.render_tiles_device(dev, poses[f][0], trans[f], W, H, D, mode, tile_rows, rank, world, fb.data_ptr(), stream)
             gather_tiles(dist, fb, full, rank, world, H, W, tile_rows, api)

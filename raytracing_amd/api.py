@@ -17,7 +17,7 @@ from typing import Iterable, Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt355.so")
+LIB_PATH = os.environ.get("RT355_LIB") or os.path.join(_HERE, "librt355.so")   # RT355_LIB: A/B builds of the same library
 
 RT_OK = 0
 ACCEL_AUTO, ACCEL_BRUTE, ACCEL_LBVH = 0, 1, 2

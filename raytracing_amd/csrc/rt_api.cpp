@@ -6,6 +6,7 @@
 // returns RT_ERR_DEVICE.
 #include "rt_internal.h"
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -157,7 +158,13 @@ int rt_scene_commit(rt_scene* s, int device, int accel_flags) {
 	const int nl = (int)(s->lights.size() / 4);
 	d.stride = ((n > 0 ? n : 1) + 63) / 64 * 64;
 	std::vector<float> planes;
-	try { flatten_planes(s->tris, d.stride, planes); } catch (...) { set_error("rt_scene_commit: out of host memory"); return RT_ERR_NOMEM; }
+	const float pad = scene_box(s->tris, d.bb_lo, d.bb_hi);
+	// Box tests are trusted only for origins within 1000 scene scales (beyond that the slab
+	// arithmetic's rounding approaches the pad) and 1e6 absolute, in scenes no larger than 1e6
+	// (keeps b * inv and o * inv finite for |inv| <= 1e30): rt_kernels.hip cast_ray_pruned.
+	d.far_guard = pad * 1e6f < 1e6f ? pad * 1e6f : 1e6f;
+	if (!(pad * 1e3f <= 1e6f)) d.far_guard = 0.f;
+	try { flatten_planes(s->tris, d.stride, pad, planes); } catch (...) { set_error("rt_scene_commit: out of host memory"); return RT_ERR_NOMEM; }
 	RT_HIP(hipMalloc(&d.planes, planes.size() * sizeof(float)));
 	RT_HIP(hipMemcpy(d.planes, planes.data(), planes.size() * sizeof(float), hipMemcpyHostToDevice));
 	RT_HIP(hipMalloc(&d.lights, (size_t)(nl > 0 ? nl : 1) * 4 * sizeof(float)));

@@ -22,13 +22,16 @@ namespace rt {
 //   plane 4  E0 = (edge0.xyz, 0)                        Source.cpp:52
 //   plane 5  E1 = (edge1.xyz, 0)                        Source.cpp:53
 //   plane 6  E2 = (edge2.xyz, 0)                        Source.cpp:54
+//   plane 7  GLO[g] = lower corner of the padded box of triangles 4g..4g+3 (entries g < stride/4)
+//   plane 8  GHI[g] = upper corner            (an empty group has GLO = +inf, GHI = -inf)
 // The `p` field of the reference record (Source.cpp:33, always == p1) is not uploaded.
-enum { PL_N = 0, PL_P1, PL_P2, PL_P3, PL_E0, PL_E1, PL_E2, PL_COUNT };
+enum { PL_N = 0, PL_P1, PL_P2, PL_P3, PL_E0, PL_E1, PL_E2, PL_GLO, PL_GHI, PL_COUNT };
+#define RT_GROUP 4
 
-// Brute force keeps the whole scene in LDS up to this many triangles (7 planes x 16 B x 512 =
-// 56 KiB, under the 64 KiB a workgroup gets without opting in to more); above it the brute-force
-// kernel reads the planes from global memory / L2 instead.
-#define RT_LDS_MAX_TRIS 512
+// Brute force keeps the whole scene in LDS up to this many triangles ((9 planes x 16 B + 4 B) x
+// 384 = 55.5 KiB, under the 64 KiB a workgroup gets without opting in to more); above it the
+// brute-force kernel reads the planes from global memory / L2 instead.
+#define RT_LDS_MAX_TRIS 384
 
 struct DevScene {
 	const float4* planes;   // PL_COUNT * stride float4
@@ -42,6 +45,10 @@ struct DevScene {
 	const int* bvh_prim;
 	int bvh_root;
 	int pad2;
+	// scene bounding box, padded (host: rt_api.cpp scene_box); +-inf when the scene has none
+	float bb_lo[3], bb_hi[3];
+	float far_guard;        // |origin| beyond this: the box tests are switched off for the ray
+	int pad3;
 };
 
 // Per-launch frame description.  Rows are addressed as LOCAL rows of this shard:
@@ -73,6 +80,8 @@ struct DeviceState {
 	int bvh_root = 0;
 	int stride = 0;
 	float build_ms = 0.f;
+	float bb_lo[3] = { 0, 0, 0 }, bb_hi[3] = { 0, 0, 0 };
+	float far_guard = 0.f;
 	// scratch framebuffer for rt_render (host output)
 	void* frame = nullptr;
 	size_t frame_bytes = 0;
@@ -100,7 +109,8 @@ int hip_fail(hipError_t e, const char* what);
 void triangle_record(vec3 p1, vec3 p2, vec3 p3, vec3 color, float shin, float* out28);
 void quad_half_record(const float T[3], const float Rdeg[3], const float S[3], const float color[3], float shin, float* out28);
 void camera_trans(const float rot_deg[3], float out16[16]);
-void flatten_planes(const std::vector<float>& tris, int stride, std::vector<float>& out);
+void flatten_planes(const std::vector<float>& tris, int stride, float pad, std::vector<float>& out);
+float scene_box(const std::vector<float>& tris, float lo[3], float hi[3]);   // returns the pad it applied
 
 // rt_kernels.hip
 DevScene dev_scene(const rt_scene* s, const DeviceState& d);

@@ -19,16 +19,21 @@
 // edge tests) are in rt_fast.inl.
 #include "rt_internal.h"
 
+#include <cstdlib>
+
 namespace rt {
 
 // Source.cpp:391 compares `t > 0.00001` with t promoted to double.  For a binary32 t this is the
 // same predicate as t > EPS_BELOW where EPS_BELOW is the largest binary32 <= 0.00001 (double):
 // (float)0.00001 = 0x3727C5AC = 9.99999974737875e-06 < 1e-5, so that float itself.
 #define RT_EPS_BELOW 9.99999974737875163555145263671875e-06f
+#define RT_PREFILTER_REL 9.5367431640625e-07f      /* 2^-20 */
 static_assert((double)RT_EPS_BELOW <= 0.00001, "EPS_BELOW must not exceed the double literal");
 
 enum { ST_IDLE = 0, ST_PRIMARY = 1, ST_BOUNCE = 2, ST_SHADOW = 3 };
 enum { CTR_PRIMARY = 0, CTR_BOUNCE, CTR_SHADOW, CTR_PLANE, CTR_POINT, CTR_EDGE, CTR_BOX, CTR_PXHIT, CTR_PXMIRROR, CTR_PXLIT, CTR_N };
+
+__host__ __device__ __forceinline__ int lds_stride_of(int n_tris) { return (n_tris + RT_GROUP - 1) / RT_GROUP * RT_GROUP; }
 
 struct Hit {
 	float t;      // closest.distance, 1e9f when nothing was hit (Source.cpp:278)
@@ -85,6 +90,126 @@ __device__ __forceinline__ Hit cast_ray_brute(TriPtr tri, int stride, int n, vec
 	return h;
 }
 
+// ---- castRay, brute force, pruned but exact -----------------------------------------------------
+// Same closest hit, bit for bit, with less work per triangle than the loop above (which stays as
+// the instrumented reference-order form used for the work counters).  Three observations:
+//  (1) A triangle can only be accepted if eps < t < closest.distance (Source.cpp:391).  Any
+//      upper bound `lim` on the distance of a possible hit may stand in for the initial 1e9:
+//      * no hit point lies outside the scene's bounding box, so t <= t_exit(box) (the box is
+//        padded on the host by 1e-3 of the scene extent and the exit distance by 1e-4, orders of
+//        magnitude above the rounding of I = o + t*d) — in a closed room this prunes every wall
+//        plane behind the wall that is actually hit;
+//      * a shadow ray only decides "is there a hit with t <= dist" (Source.cpp:476), so its
+//        limit is the float after dist and it may stop at its first accepted hit.
+//  (2) t > eps already implies !(t < 0) (Source.cpp:385), and the self-skip (Source.cpp:302) only
+//      matters for a triangle that would otherwise be accepted, so both leave the per-triangle path.
+//  (3) For primary rays the numerator dot(p1 - camera, n) of Source.cpp:383 is the same for every
+//      pixel: it is computed once per workgroup (same operations, same bits) and read from LDS.
+// Edge tests and acceptance for ONE triangle whose exact t is known (Source.cpp:389-396).
+template <typename TriPtr>
+__device__ __forceinline__ void accept_triangle(TriPtr tri, int stride, int i, vec3 nn, vec3 p1, vec3 o, vec3 d, float t,
+                                                bool cand, int skip, bool first_only, Hit& h, float& lim, float& lim_hi) {
+	const vec3 I = make3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);   // Source.cpp:389
+	const float4 E0 = tri[PL_E0 * stride + i];
+	const bool c0 = cand && (dot(nn, cross(xyz(E0), I - p1)) > 0.0f);    // Source.cpp:392
+	if (__builtin_amdgcn_ballot_w64(c0) == 0) return;
+	const float4 P24 = tri[PL_P2 * stride + i];
+	const float4 E1 = tri[PL_E1 * stride + i];
+	const bool c1 = c0 && (dot(nn, cross(xyz(E1), I - xyz(P24))) > 0.0f);   // Source.cpp:393
+	if (__builtin_amdgcn_ballot_w64(c1) == 0) return;
+	const float4 P34 = tri[PL_P3 * stride + i];
+	const float4 E2 = tri[PL_E2 * stride + i];
+	const bool c2 = c1 && (dot(nn, cross(xyz(E2), I - xyz(P34))) > 0.0f);   // Source.cpp:394
+	if (c2 && i != skip) {                                                  // Source.cpp:302, 396
+		h.t = t; h.idx = i; h.p = I;
+		lim = first_only ? -1.0f : t;
+		lim_hi = lim + fabsf(lim) * RT_PREFILTER_REL;
+	}
+}
+
+// The loop itself, over groups of RT_GROUP consecutive triangles.
+//  (4) Each group has a padded bounding box (host: flatten_planes).  A hit point lies in its
+//      triangle's box up to rounding that the pad exceeds by orders of magnitude, so a group whose
+//      box the ray misses — or only meets beyond `lim` — is skipped as a whole (one slab test per
+//      group instead of RT_GROUP plane tests plus the edge terms of every plane the ray happens
+//      to cross: the infinite planes of a small object are crossed by most rays of a frame).
+//  (5) Per triangle the wave first forms ta = num * rcp(den): v_rcp_f32 is within 1 ulp, so ta is
+//      within 3 * 2^-24 of the correctly rounded quotient t whenever rcp(den) is a normal number.
+//      A triangle with ta outside [eps*(1 - 2^-20), lim*(1 + 2^-20)] therefore cannot satisfy
+//      eps < t < lim and is dropped without the IEEE division; everything else (including NaN and
+//      any den whose reciprocal is not a normal float) goes on to the exact t = num / den and the
+//      reference's own comparisons.
+// Neither filter ever decides a hit; both only skip work, and NaNs always fall through to the
+// exact path.  `cull` is false for rays whose origin is too far out for the slab arithmetic.
+template <bool PRIMARY, typename TriPtr>
+__device__ __forceinline__ Hit cast_ray_pruned(TriPtr tri, int stride, int n, const float* num0, vec3 o, vec3 d,
+                                               int skip, float lim, bool first_only, bool cull) {
+	Hit h;
+	h.t = 1e9f;
+	h.idx = -1;
+	h.p = make3(0.f, 0.f, 0.f);
+	float lim_hi = lim + fabsf(lim) * RT_PREFILTER_REL;
+	const float eps_lo = RT_EPS_BELOW * (1.0f - RT_PREFILTER_REL);
+	// Slab arithmetic t = b * inv - o * inv must stay finite: a direction component below 1e-30
+	// is widened to 1e-30 (its slab interval is then ~(-1e28, 1e28) around any origin inside the
+	// slab, empty for origins outside), and the host switches culling off (far_guard) for origins
+	// or scenes large enough for the products to overflow or to lose the pad to rounding.
+	const vec3 ds = make3(fabsf(d.x) < 1e-30f ? 1e-30f : d.x, fabsf(d.y) < 1e-30f ? 1e-30f : d.y, fabsf(d.z) < 1e-30f ? 1e-30f : d.z);
+	const vec3 inv = make3(__builtin_amdgcn_rcpf(ds.x), __builtin_amdgcn_rcpf(ds.y), __builtin_amdgcn_rcpf(ds.z));
+	const vec3 oi = make3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
+	for (int g = 0; g * RT_GROUP < n; g++) {
+		const float4 lo = tri[PL_GLO * stride + g];
+		const float4 hi = tri[PL_GHI * stride + g];
+		const float x0 = __builtin_fmaf(lo.x, inv.x, oi.x), x1 = __builtin_fmaf(hi.x, inv.x, oi.x);
+		const float y0 = __builtin_fmaf(lo.y, inv.y, oi.y), y1 = __builtin_fmaf(hi.y, inv.y, oi.y);
+		const float z0 = __builtin_fmaf(lo.z, inv.z, oi.z), z1 = __builtin_fmaf(hi.z, inv.z, oi.z);
+		// v_min/v_max drop NaN operands (0 * inf on a slab the ray lies in): that axis then does not constrain
+		const float tmin = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
+		const float tmax = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), lim_hi));
+		const bool inbox = !(tmin > tmax) || !cull;
+		if (__builtin_amdgcn_ballot_w64(inbox) == 0) continue;
+#pragma unroll
+		for (int k = 0; k < RT_GROUP; k++) {
+			const int i = g * RT_GROUP + k;
+			if (i >= n) break;
+			const vec3 nn = xyz(tri[PL_N * stride + i]);
+			vec3 p1 = make3(0.f, 0.f, 0.f);
+			float num;
+			if constexpr (PRIMARY) {
+				num = num0[i];
+			} else {
+				p1 = xyz(tri[PL_P1 * stride + i]);
+				num = dot(p1 - o, nn);
+			}
+			const float den = dot(d, nn);
+			const float r = __builtin_amdgcn_rcpf(den);
+			const float ta = num * r;
+			const bool normal = __builtin_amdgcn_classf(r, 0x108);          // +-normal
+			const bool maybe = inbox && (!normal || (!(ta < eps_lo) && !(ta > lim_hi)));
+			if (__builtin_amdgcn_ballot_w64(maybe) == 0) continue;
+			const float t = num / den;                                      // Source.cpp:383
+			const bool cand = maybe && (t > RT_EPS_BELOW) && (t < lim);     // Source.cpp:385, 391
+			if (__builtin_amdgcn_ballot_w64(cand) == 0) continue;
+			if constexpr (PRIMARY) p1 = xyz(tri[PL_P1 * stride + i]);
+			accept_triangle(tri, stride, i, nn, p1, o, d, t, cand, skip, first_only, h, lim, lim_hi);
+		}
+	}
+	return h;
+}
+
+// Upper bound on the distance of any hit: where the ray leaves the (padded) scene box.
+__device__ __forceinline__ float exit_bound(const DevScene& sc, vec3 o, vec3 d) {
+	const float inf = __builtin_huge_valf();
+	float tx = ((d.x > 0.f ? sc.bb_hi[0] : sc.bb_lo[0]) - o.x) * __builtin_amdgcn_rcpf(d.x);
+	float ty = ((d.y > 0.f ? sc.bb_hi[1] : sc.bb_lo[1]) - o.y) * __builtin_amdgcn_rcpf(d.y);
+	float tz = ((d.z > 0.f ? sc.bb_hi[2] : sc.bb_lo[2]) - o.z) * __builtin_amdgcn_rcpf(d.z);
+	tx = (d.x != 0.f) ? tx : inf;
+	ty = (d.y != 0.f) ? ty : inf;
+	tz = (d.z != 0.f) ? tz : inf;
+	const float te = fminf(fminf(tx, ty), tz);           // fminf drops NaN operands
+	return te + fabsf(te) * 1e-4f;                       // NaN (all-NaN ray) is dropped by the caller's fminf
+}
+
 // ---- pixel <-> work index ------------------------------------------------------------------
 // Work items are numbered tile-major: item g -> tile g/64 (tiles run left to right, then up),
 // pixel g%64 inside the 8x8 tile.  A wave owns `tiles_per_wave` consecutive tiles.
@@ -137,9 +262,12 @@ __device__ __forceinline__ void flush_counters(unsigned long long* g, const unsi
 // ---- the render kernel -----------------------------------------------------------------------
 // ACCEL 0: brute force with the scene in LDS; 1: brute force reading the global planes (scenes
 // too large for LDS); 2: LBVH traversal (rt_lbvh.inl).
+// `shadow`: the lane's ray is a shadow ray towards a light at distance `dist`.
+// `all_primary` (wave-uniform): every live lane holds a primary ray from the camera.
 template <int ACCEL, bool COUNT>
-__device__ __forceinline__ Hit trace(const DevScene& sc, const float4* lds_tri, int lds_stride, vec3 o, vec3 d,
-                                     int skip, bool live, LaneCounters& lc);
+__device__ __forceinline__ Hit trace(const DevScene& sc, const float4* lds_tri, int lds_stride, const float* lds_num0,
+                                     vec3 o, vec3 d, int skip, bool live, bool shadow, float dist, bool all_primary,
+                                     LaneCounters& lc);
 
 } // namespace rt
 
@@ -148,14 +276,29 @@ __device__ __forceinline__ Hit trace(const DevScene& sc, const float4* lds_tri, 
 namespace rt {
 
 template <int ACCEL, bool COUNT>
-__device__ __forceinline__ Hit trace(const DevScene& sc, const float4* lds_tri, int lds_stride, vec3 o, vec3 d,
-                                     int skip, bool live, LaneCounters& lc) {
-	if constexpr (ACCEL == 0) {
-		return cast_ray_brute<COUNT>(lds_tri, lds_stride, sc.n_tris, o, d, skip, live, lc);
-	} else if constexpr (ACCEL == 1) {
-		return cast_ray_brute<COUNT>(sc.planes, sc.stride, sc.n_tris, o, d, skip, live, lc);
+__device__ __forceinline__ Hit trace(const DevScene& sc, const float4* lds_tri, int lds_stride, const float* lds_num0,
+                                     vec3 o, vec3 d, int skip, bool live, bool shadow, float dist, bool all_primary,
+                                     LaneCounters& lc) {
+	if constexpr (ACCEL == 2) {
+		return cast_ray_lbvh<COUNT>(sc, o, d, skip, live, shadow, dist, lc);
+	} else if constexpr (COUNT) {
+		// instrumented, reference-order loop: the counters follow Source.cpp's own short-circuits
+		if constexpr (ACCEL == 0) return cast_ray_brute<true>(lds_tri, lds_stride, sc.n_tris, o, d, skip, live, lc);
+		else return cast_ray_brute<true>(sc.planes, sc.stride, sc.n_tris, o, d, skip, live, lc);
 	} else {
-		return cast_ray_lbvh<COUNT>(sc, o, d, skip, live, lc);
+		// limit of the search (see cast_ray_pruned); idle lanes get a limit nothing passes
+		const bool near = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) < sc.far_guard;   // false for NaN too
+		float lim = near ? fminf(exit_bound(sc, o, d), 1e9f) : 1e9f;         // 1e9: Source.cpp:278
+		if (shadow) lim = fminf(lim, __uint_as_float(__float_as_uint(dist) + 1u));   // first float > dist (dist >= +0)
+		lim = fminf(lim, 1e9f);                                              // (dist == inf -> NaN -> dropped)
+		if (!live) lim = -1.0f;
+		const bool cull = near;
+		if constexpr (ACCEL == 0) {
+			if (all_primary) return cast_ray_pruned<true>(lds_tri, lds_stride, sc.n_tris, lds_num0, o, d, skip, lim, false, cull);
+			return cast_ray_pruned<false>(lds_tri, lds_stride, sc.n_tris, lds_num0, o, d, skip, lim, shadow, cull);
+		} else {
+			return cast_ray_pruned<false>(sc.planes, sc.stride, sc.n_tris, nullptr, o, d, skip, lim, shadow, cull);
+		}
 	}
 }
 
@@ -169,12 +312,18 @@ __device__ __forceinline__ float4 tri_plane(const DevScene& sc, const float4* ld
 template <int ACCEL, bool COUNT>
 __global__ void __launch_bounds__(256) render_kernel(DevScene sc, FrameParams fp, int tiles_per_wave) {
 	extern __shared__ float4 s_tri[];
-	const int lds_stride = sc.n_tris;
+	const int lds_stride = lds_stride_of(sc.n_tris);
+	float* s_num0 = (float*)(s_tri + PL_COUNT * lds_stride);
+	const vec3 cam = make3(fp.cam[0], fp.cam[1], fp.cam[2]);
 	if constexpr (ACCEL == 0) {
 		// stage all planes: consecutive lanes copy consecutive float4 (coalesced 1 KiB per wave op)
+		// (the device planes are zero-padded to a multiple of 64 triangles, so the batch padding reads zeros)
 		for (int k = 0; k < PL_COUNT; k++)
-			for (int i = threadIdx.x; i < sc.n_tris; i += blockDim.x)
+			for (int i = threadIdx.x; i < lds_stride; i += blockDim.x)
 				s_tri[k * lds_stride + i] = sc.planes[k * sc.stride + i];
+		// numerator of Source.cpp:383 for rays that start at the camera
+		for (int i = threadIdx.x; i < lds_stride; i += blockDim.x)
+			s_num0[i] = dot(xyz(sc.planes[PL_P1 * sc.stride + i]) - cam, xyz(sc.planes[PL_N * sc.stride + i]));
 		__syncthreads();
 	}
 
@@ -185,8 +334,6 @@ __global__ void __launch_bounds__(256) render_kernel(DevScene sc, FrameParams fp
 	long long next = wave * tiles_per_wave * 64;                   // wave-uniform cursor
 	long long end = next + (long long)tiles_per_wave * 64;
 	if (end > n_items) end = n_items;
-
-	const vec3 cam = make3(fp.cam[0], fp.cam[1], fp.cam[2]);
 
 	// per-lane ray state
 	int stage = ST_IDLE;
@@ -238,7 +385,9 @@ __global__ void __launch_bounds__(256) render_kernel(DevScene sc, FrameParams fp
 		}
 
 		// ---- the one closest-hit loop ---------------------------------------------------------
-		const Hit h = trace<ACCEL, COUNT>(sc, s_tri, lds_stride, o, d, skip, live, lc);
+		const bool all_primary = __builtin_amdgcn_ballot_w64(live && stage != ST_PRIMARY) == 0;
+		const Hit h = trace<ACCEL, COUNT>(sc, s_tri, lds_stride, s_num0, o, d, skip, live, stage == ST_SHADOW, dist,
+		                                  all_primary, lc);
 		const bool hit = h.idx >= 0;
 
 		// ---- stage transitions ----------------------------------------------------------------
@@ -346,10 +495,10 @@ __global__ void __launch_bounds__(256) render_kernel(DevScene sc, FrameParams fp
 template <int ACCEL>
 __global__ void __launch_bounds__(256) cast_rays_kernel(DevScene sc, int n, const float* __restrict__ rays7, float* __restrict__ out6) {
 	extern __shared__ float4 s_tri[];
-	const int lds_stride = sc.n_tris;
+	const int lds_stride = lds_stride_of(sc.n_tris);
 	if constexpr (ACCEL == 0) {
 		for (int k = 0; k < PL_COUNT; k++)
-			for (int i = threadIdx.x; i < sc.n_tris; i += blockDim.x)
+			for (int i = threadIdx.x; i < lds_stride; i += blockDim.x)
 				s_tri[k * lds_stride + i] = sc.planes[k * sc.stride + i];
 		__syncthreads();
 	}
@@ -365,7 +514,7 @@ __global__ void __launch_bounds__(256) cast_rays_kernel(DevScene sc, int n, cons
 		skip = (sk >= 0.0f && sk < (float)sc.n_tris) ? (int)sk : -1;
 	}
 	LaneCounters lc = { 0, 0, 0, 0 };
-	const Hit h = trace<ACCEL, false>(sc, s_tri, lds_stride, o, d, skip, live, lc);
+	const Hit h = trace<ACCEL, false>(sc, s_tri, lds_stride, nullptr, o, d, skip, live, false, 0.f, false, lc);
 	if (live) {
 		float* w = out6 + (size_t)r * 6;
 		w[0] = h.idx >= 0 ? 1.0f : 0.0f;
@@ -389,13 +538,16 @@ DevScene dev_scene(const rt_scene* s, const DeviceState& d) {
 	sc.bvh_prim = (const int*)d.bvh_prim;
 	sc.bvh_root = d.bvh_root;
 	sc.pad2 = 0;
+	sc.far_guard = d.far_guard;
+	sc.pad3 = 0;
+	for (int k = 0; k < 3; k++) { sc.bb_lo[k] = d.bb_lo[k]; sc.bb_hi[k] = d.bb_hi[k]; }
 	return sc;
 }
 
 static int pick_tiles_per_wave(long long tiles) {
 	// Enough waves to fill 256 CUs x 4 SIMDs several times over, long enough runs for the
 	// regeneration to have something to refill with.
-	const long long target_waves = 1024 * 8;
+	const long long target_waves = 1024 * 32;
 	long long tpw = (tiles + target_waves - 1) / target_waves;
 	if (tpw < 1) tpw = 1;
 	if (tpw > 64) tpw = 64;
@@ -408,14 +560,17 @@ int launch_render(const DevScene& sc, const FrameParams& fp, int accel, int rend
 	const long long tiles = (long long)((fp.width + 7) / 8) * ((fp.local_rows + 7) / 8);
 	int tpw = fp.tiles_per_wave > 0 ? fp.tiles_per_wave : pick_tiles_per_wave(tiles);
 	const long long waves = (tiles + tpw - 1) / tpw;
-	const long long blocks = (waves + 3) / 4;
+	static const int env_block = [] { const char* e = getenv("RT355_BLOCK_THREADS"); int v = e ? atoi(e) : 0; return (v == 64 || v == 128 || v == 256) ? v : 0; }();
+	const int threads = env_block ? env_block : 256;
+	const int wpb = threads / 64;
+	const long long blocks = (waves + wpb - 1) / wpb;
 	if (blocks > 0x7fffffffLL) { set_error("rt_render: frame too large (%lld workgroups)", blocks); return RT_ERR_LIMIT; }
-	const dim3 grid((unsigned)blocks), block(256);
+	const dim3 grid((unsigned)blocks), block((unsigned)threads);
 	if (accel == RT_ACCEL_LBVH) {
 		if (count) hipLaunchKernelGGL((render_kernel<2, true>), grid, block, 0, stream, sc, fp, tpw);
 		else hipLaunchKernelGGL((render_kernel<2, false>), grid, block, 0, stream, sc, fp, tpw);
 	} else if (sc.n_tris <= RT_LDS_MAX_TRIS) {
-		const size_t lds = (size_t)PL_COUNT * sc.n_tris * sizeof(float4);
+		const size_t lds = (size_t)lds_stride_of(sc.n_tris) * (PL_COUNT * sizeof(float4) + sizeof(float));
 		if (count) hipLaunchKernelGGL((render_kernel<0, true>), grid, block, lds, stream, sc, fp, tpw);
 		else hipLaunchKernelGGL((render_kernel<0, false>), grid, block, lds, stream, sc, fp, tpw);
 	} else {
@@ -433,7 +588,7 @@ int launch_cast_rays(const DevScene& sc, int accel, int n, const float* d_rays7,
 	if (accel == RT_ACCEL_LBVH) {
 		hipLaunchKernelGGL((cast_rays_kernel<2>), grid, block, 0, stream, sc, n, d_rays7, d_out6);
 	} else if (sc.n_tris <= RT_LDS_MAX_TRIS) {
-		const size_t lds = (size_t)PL_COUNT * sc.n_tris * sizeof(float4);
+		const size_t lds = (size_t)lds_stride_of(sc.n_tris) * (PL_COUNT * sizeof(float4) + sizeof(float));
 		hipLaunchKernelGGL((cast_rays_kernel<0>), grid, block, lds, stream, sc, n, d_rays7, d_out6);
 	} else {
 		hipLaunchKernelGGL((cast_rays_kernel<1>), grid, block, 0, stream, sc, n, d_rays7, d_out6);

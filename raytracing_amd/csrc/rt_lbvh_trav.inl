@@ -4,8 +4,8 @@
 namespace rt {
 
 template <bool COUNT>
-__device__ __forceinline__ Hit cast_ray_lbvh(const DevScene& sc, vec3 o, vec3 d, int skip, bool live, LaneCounters& lc) {
-	(void)sc; (void)o; (void)d; (void)skip; (void)live; (void)lc;
+__device__ __forceinline__ Hit cast_ray_lbvh(const DevScene& sc, vec3 o, vec3 d, int skip, bool live, bool shadow, float dist, LaneCounters& lc) {
+	(void)sc; (void)o; (void)d; (void)skip; (void)live; (void)shadow; (void)dist; (void)lc;
 	Hit h;
 	h.t = 1e9f;
 	h.idx = -1;

@@ -122,8 +122,41 @@ void camera_trans(const float rot_deg[3], float out16[16]) {
 	memcpy(out16, &t, sizeof(float) * 16);
 }
 
-void flatten_planes(const std::vector<float>& tris, int stride, std::vector<float>& out) {
+// Bounding box of every triangle vertex, padded by 1e-3 of the scene's scale.  The render kernels
+// use boxes only to skip work that cannot produce a hit (rt_kernels.hip), never to decide one.
+// A scene with a non-finite vertex gets an infinite box (no pruning).  Returns the pad.
+float scene_box(const std::vector<float>& tris, float lo[3], float hi[3]) {
+	const float inf = __builtin_huge_valf();
+	const size_t n = tris.size() / RT_TRI_FLOATS;
+	bool finite = n > 0;
+	float l[3] = { inf, inf, inf }, h[3] = { -inf, -inf, -inf };
+	for (size_t i = 0; i < n && finite; i++) {
+		const float* t = tris.data() + i * RT_TRI_FLOATS + 6;      // p1 p2 p3
+		for (int v = 0; v < 9; v++) {
+			const float c = t[v];
+			if (!(c - c == 0.0f)) { finite = false; break; }
+			if (c < l[v % 3]) l[v % 3] = c;
+			if (c > h[v % 3]) h[v % 3] = c;
+		}
+	}
+	if (!finite) {
+		for (int k = 0; k < 3; k++) { lo[k] = -inf; hi[k] = inf; }
+		return inf;
+	}
+	float scale = 1e-30f;
+	for (int k = 0; k < 3; k++) {
+		if (h[k] - l[k] > scale) scale = h[k] - l[k];
+		if (fabsf(l[k]) > scale) scale = fabsf(l[k]);
+		if (fabsf(h[k]) > scale) scale = fabsf(h[k]);
+	}
+	const float pad = scale * 1e-3f;
+	for (int k = 0; k < 3; k++) { lo[k] = l[k] - pad; hi[k] = h[k] + pad; }
+	return pad;
+}
+
+void flatten_planes(const std::vector<float>& tris, int stride, float pad, std::vector<float>& out) {
 	const int n = (int)(tris.size() / RT_TRI_FLOATS);
+	const float inf = __builtin_huge_valf();
 	out.assign((size_t)PL_COUNT * stride * 4, 0.0f);
 	auto plane = [&](int k, int i) { return out.data() + ((size_t)k * stride + i) * 4; };
 	for (int i = 0; i < n; i++) {
@@ -138,6 +171,26 @@ void flatten_planes(const std::vector<float>& tris, int stride, std::vector<floa
 		q = plane(PL_E0, i); q[0] = e0[0]; q[1] = e0[1]; q[2] = e0[2];
 		q = plane(PL_E1, i); q[0] = e1[0]; q[1] = e1[1]; q[2] = e1[2];
 		q = plane(PL_E2, i); q[0] = e2[0]; q[1] = e2[1]; q[2] = e2[2];
+	}
+	// padded boxes of groups of RT_GROUP consecutive triangles
+	for (int g = 0; g * RT_GROUP < stride; g++) {
+		float l[3] = { inf, inf, inf }, h[3] = { -inf, -inf, -inf };
+		bool finite = pad - pad == 0.0f;
+		for (int i = g * RT_GROUP; i < (g + 1) * RT_GROUP && i < n; i++) {
+			const float* v = tris.data() + (size_t)i * RT_TRI_FLOATS + 6;
+			for (int c = 0; c < 9; c++) {
+				if (!(v[c] - v[c] == 0.0f)) finite = false;
+				if (v[c] < l[c % 3]) l[c % 3] = v[c];
+				if (v[c] > h[c % 3]) h[c % 3] = v[c];
+			}
+		}
+		float* ql = plane(PL_GLO, g);
+		float* qh = plane(PL_GHI, g);
+		const bool empty = g * RT_GROUP >= n;
+		for (int k = 0; k < 3; k++) {
+			ql[k] = empty ? inf : (finite ? l[k] - pad : -inf);
+			qh[k] = empty ? -inf : (finite ? h[k] + pad : inf);
+		}
 	}
 }
 
