@@ -103,6 +103,12 @@ int rt_scene_commit(rt_scene* s, int device, int accel_flags);
 /* Milliseconds the last commit on `device` spent building the LBVH on the GPU (0 for brute). */
 int rt_scene_build_ms(const rt_scene* s, int device, float* out_ms);
 
+/* Copy out the LBVH built by the last commit on `device` (tests, tools): up to `capacity` nodes of
+ * 16 floats each — {left box lo xyz, hi xyz, right box lo xyz, hi xyz, left ref, right ref, 0, 0},
+ * refs as int bits: >= 0 internal node index, < 0 leaf holding triangle ~ref; node 0 is the root.
+ * Returns the number of nodes (triangle count - 1), or 0 for a brute-force commit. */
+int rt_scene_get_bvh(const rt_scene* s, int device, float* out_nodes16, int capacity);
+
 /* The acceleration structure the last commit on `device` chose: RT_ACCEL_BRUTE or RT_ACCEL_LBVH. */
 int rt_scene_accel(const rt_scene* s, int device);
 

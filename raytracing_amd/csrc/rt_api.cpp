@@ -159,6 +159,7 @@ int rt_scene_commit(rt_scene* s, int device, int accel_flags) {
 	d.stride = ((n > 0 ? n : 1) + 63) / 64 * 64;
 	std::vector<float> planes;
 	const float pad = scene_box(s->tris, d.bb_lo, d.bb_hi);
+	d.pad = pad;
 	// Box tests are trusted only for origins within 1000 scene scales (beyond that the slab
 	// arithmetic's rounding approaches the pad) and 1e6 absolute, in scenes no larger than 1e6
 	// (keeps b * inv and o * inv finite for |inv| <= 1e30): rt_kernels.hip cast_ray_pruned.
@@ -175,7 +176,8 @@ int rt_scene_commit(rt_scene* s, int device, int accel_flags) {
 	d.build_ms = 0.f;
 	if (d.accel == RT_ACCEL_LBVH) {
 		int rc = lbvh_build(s, d, nullptr);
-		if (rc != RT_OK) return rc;
+		if (rc == RT_ERR_LIMIT && accel_flags == RT_ACCEL_AUTO) d.accel = RT_ACCEL_BRUTE;   // e.g. a non-finite vertex
+		else if (rc != RT_OK) return rc;
 	}
 	d.valid = true;
 	if (s->first_device < 0 || !s->dev.count(s->first_device) || !s->dev[s->first_device].valid) s->first_device = device;
@@ -188,6 +190,22 @@ int rt_scene_build_ms(const rt_scene* s, int device, float* out_ms) {
 	if (it == s->dev.end() || !it->second.valid) { set_error("rt_scene_build_ms: not committed on device %d", device); return RT_ERR_STATE; }
 	*out_ms = it->second.build_ms;
 	return RT_OK;
+}
+
+int rt_scene_get_bvh(const rt_scene* s, int device, float* out_nodes16, int capacity) {
+	if (!s || capacity < 0 || (capacity > 0 && !out_nodes16)) { set_error("rt_scene_get_bvh: bad argument"); return RT_ERR_INVALID; }
+	auto it = s->dev.find(device);
+	if (it == s->dev.end() || !it->second.valid) { set_error("rt_scene_get_bvh: not committed on device %d", device); return RT_ERR_STATE; }
+	const DeviceState& d = it->second;
+	if (d.accel != RT_ACCEL_LBVH || !d.bvh_nodes) return 0;
+	const int nodes = (int)(s->tris.size() / RT_TRI_FLOATS) - 1;
+	const int k = nodes < capacity ? nodes : capacity;
+	if (k > 0) {
+		DeviceGuard g(device);
+		if (!g.ok) return g.rc;
+		RT_HIP(hipMemcpy(out_nodes16, d.bvh_nodes, (size_t)k * 16 * sizeof(float), hipMemcpyDeviceToHost));
+	}
+	return nodes;
 }
 
 int rt_scene_accel(const rt_scene* s, int device) {

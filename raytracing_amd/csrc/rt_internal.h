@@ -82,6 +82,7 @@ struct DeviceState {
 	float build_ms = 0.f;
 	float bb_lo[3] = { 0, 0, 0 }, bb_hi[3] = { 0, 0, 0 };
 	float far_guard = 0.f;
+	float pad = 0.f;
 	// scratch framebuffer for rt_render (host output)
 	void* frame = nullptr;
 	size_t frame_bytes = 0;

@@ -280,7 +280,7 @@ __device__ __forceinline__ Hit trace(const DevScene& sc, const float4* lds_tri, 
                                      vec3 o, vec3 d, int skip, bool live, bool shadow, float dist, bool all_primary,
                                      LaneCounters& lc) {
 	if constexpr (ACCEL == 2) {
-		return cast_ray_lbvh<COUNT>(sc, o, d, skip, live, shadow, dist, lc);
+		return cast_ray_lbvh<COUNT>(sc, (int*)lds_tri, o, d, skip, live, shadow, dist, lc);
 	} else if constexpr (COUNT) {
 		// instrumented, reference-order loop: the counters follow Source.cpp's own short-circuits
 		if constexpr (ACCEL == 0) return cast_ray_brute<true>(lds_tri, lds_stride, sc.n_tris, o, d, skip, live, lc);
@@ -567,8 +567,9 @@ int launch_render(const DevScene& sc, const FrameParams& fp, int accel, int rend
 	if (blocks > 0x7fffffffLL) { set_error("rt_render: frame too large (%lld workgroups)", blocks); return RT_ERR_LIMIT; }
 	const dim3 grid((unsigned)blocks), block((unsigned)threads);
 	if (accel == RT_ACCEL_LBVH) {
-		if (count) hipLaunchKernelGGL((render_kernel<2, true>), grid, block, 0, stream, sc, fp, tpw);
-		else hipLaunchKernelGGL((render_kernel<2, false>), grid, block, 0, stream, sc, fp, tpw);
+		const size_t lds = (size_t)RT_STACK_LDS * threads * sizeof(int);
+		if (count) hipLaunchKernelGGL((render_kernel<2, true>), grid, block, lds, stream, sc, fp, tpw);
+		else hipLaunchKernelGGL((render_kernel<2, false>), grid, block, lds, stream, sc, fp, tpw);
 	} else if (sc.n_tris <= RT_LDS_MAX_TRIS) {
 		const size_t lds = (size_t)lds_stride_of(sc.n_tris) * (PL_COUNT * sizeof(float4) + sizeof(float));
 		if (count) hipLaunchKernelGGL((render_kernel<0, true>), grid, block, lds, stream, sc, fp, tpw);
@@ -586,7 +587,7 @@ int launch_cast_rays(const DevScene& sc, int accel, int n, const float* d_rays7,
 	if (n <= 0) return RT_OK;
 	const dim3 grid((unsigned)((n + 255) / 256)), block(256);
 	if (accel == RT_ACCEL_LBVH) {
-		hipLaunchKernelGGL((cast_rays_kernel<2>), grid, block, 0, stream, sc, n, d_rays7, d_out6);
+		hipLaunchKernelGGL((cast_rays_kernel<2>), grid, block, (size_t)RT_STACK_LDS * 256 * sizeof(int), stream, sc, n, d_rays7, d_out6);
 	} else if (sc.n_tris <= RT_LDS_MAX_TRIS) {
 		const size_t lds = (size_t)lds_stride_of(sc.n_tris) * (PL_COUNT * sizeof(float4) + sizeof(float));
 		hipLaunchKernelGGL((cast_rays_kernel<0>), grid, block, lds, stream, sc, n, d_rays7, d_out6);

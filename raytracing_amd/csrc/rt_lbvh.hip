@@ -1,19 +1,252 @@
-// rt_lbvh.hip — GPU LBVH build (Morton sort + Karras).  Placeholder until the build lands.
+// rt_lbvh.hip — GPU-built linear BVH for large scenes (BASELINE config 4: 100k triangles).
+//
+// The reference has no acceleration structure: castRay walks every triangle (Source.cpp:301).
+// north_star replaces that O(N) walk for large scenes by an LBVH built ON the GPU:
+//
+//   1. k_morton      one lane per triangle: centroid of its vertex box, normalised by the scene
+//                    box, 10 bits per axis interleaved to a 30-bit Morton code; key =
+//                    (code << 32) | triangle index, so keys are unique (Karras 2012, §4: "augment
+//                    each key with its index") and equal codes still split into a balanced subtree.
+//   2. radix sort    rocPRIM device radix sort of the 64-bit keys (bits 0..61).
+//   3. k_karras      one lane per internal node i in [0, N-2]: direction, range and split from
+//                    the longest-common-prefix function delta(i, j) = clz(key_i ^ key_j)
+//                    (Karras 2012, Alg. in §3); writes the two child references and the parent
+//                    links.  Node 0 is the root.
+//   4. k_refit       one lane per leaf walks to the root; the second lane to arrive at a node
+//                    (atomic counter) merges the two child boxes and carries on.  Each node stores
+//                    ITS CHILDREN's boxes, so one 64-byte fetch during traversal yields both slab
+//                    tests.
+//
+// Node (4 x float4 = 64 B, 64-byte aligned):
+//   q0 = (L.lo.x, L.lo.y, L.lo.z, L.hi.x)   q1 = (L.hi.y, L.hi.z, R.lo.x, R.lo.y)
+//   q2 = (R.lo.z, R.hi.x, R.hi.y, R.hi.z)   q3 = (left ref, right ref, 0, 0) as int bits
+// A child reference >= 0 is an internal node index; < 0 is a leaf holding triangle ~ref.
+// Leaf boxes are the triangle's vertex box padded by the scene pad (1e-3 of the scene scale): boxes
+// only ever skip work, the triangle test at the leaf is the reference's own arithmetic.
+//
+// Cross-workgroup hand-off in k_refit (MI355X: per-CU L1 is not coherent, per-XCD L2s are not
+// coherent with each other): the arriving lane stores its box with agent-scope (sc1, write-through)
+// stores, issues an agent release fence + explicit vmcnt(0) wait, then the returning agent-scope
+// atomic add; the second arriver issues an agent acquire fence and reads the sibling's slots with
+// agent-scope (L1-bypassing) loads.
 #include "rt_internal.h"
+
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
 
 namespace rt {
 
-int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
-	(void)s; (void)d; (void)stream;
-	set_error("LBVH build is not available in this build");
-	return RT_ERR_LIMIT;
+namespace {
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ unsigned int expand_bits10(unsigned int v) {
+	// 10 bits -> every third bit of 30
+	v = (v * 0x00010001u) & 0xFF0000FFu;
+	v = (v * 0x00000101u) & 0x0F00F00Fu;
+	v = (v * 0x00000011u) & 0xC30C30C3u;
+	v = (v * 0x00000005u) & 0x49249249u;
+	return v;
 }
+
+__device__ __forceinline__ void tri_box(const float4* __restrict__ planes, int stride, int i, float lo[3], float hi[3]) {
+	const float4 a = planes[PL_P1 * stride + i], b = planes[PL_P2 * stride + i], c = planes[PL_P3 * stride + i];
+	lo[0] = fminf(a.x, fminf(b.x, c.x)); hi[0] = fmaxf(a.x, fmaxf(b.x, c.x));
+	lo[1] = fminf(a.y, fminf(b.y, c.y)); hi[1] = fmaxf(a.y, fmaxf(b.y, c.y));
+	lo[2] = fminf(a.z, fminf(b.z, c.z)); hi[2] = fmaxf(a.z, fmaxf(b.z, c.z));
+}
+
+struct BoxF { float lo[3], hi[3]; };
+
+__global__ void __launch_bounds__(256) k_morton(const float4* __restrict__ planes, int stride, int n, BoxF scene, u64* __restrict__ keys) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	float lo[3], hi[3];
+	tri_box(planes, stride, i, lo, hi);
+	unsigned int code = 0;
+#pragma unroll
+	for (int k = 0; k < 3; k++) {
+		const float ext = scene.hi[k] - scene.lo[k];
+		const float c = 0.5f * (lo[k] + hi[k]);
+		float u = ext > 0.f ? (c - scene.lo[k]) / ext : 0.5f;
+		u = fminf(fmaxf(u * 1024.0f, 0.0f), 1023.0f);
+		code |= expand_bits10((unsigned int)u) << (2 - k);
+	}
+	keys[i] = ((u64)code << 32) | (unsigned int)i;
+}
+
+// delta(i, j): common-prefix length of keys i and j, -1 outside [0, n)
+__device__ __forceinline__ int delta(const u64* __restrict__ keys, int n, int i, int j) {
+	if (j < 0 || j >= n) return -1;
+	return __clzll((long long)(keys[i] ^ keys[j]));      // keys are unique, the xor is never 0
+}
+
+__global__ void __launch_bounds__(256) k_karras(const u64* __restrict__ keys, int n, float4* __restrict__ nodes,
+                                               int* __restrict__ parent_int, int* __restrict__ parent_leaf) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n - 1) return;
+	// direction of the range
+	const int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+	const int dmin = delta(keys, n, i, i - d);
+	int lmax = 2;
+	while (delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+	int l = 0;
+	for (int t = lmax >> 1; t >= 1; t >>= 1)
+		if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+	const int j = i + l * d;
+	// split position
+	const int dnode = delta(keys, n, i, j);
+	int s = 0;
+	int t = l;
+	do {
+		t = (t + 1) >> 1;
+		if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+	} while (t > 1);
+	const int gamma = i + s * d + min(d, 0);
+	const int first = min(i, j), last = max(i, j);
+	const int left = (first == gamma) ? ~(int)(unsigned int)keys[gamma] : gamma;
+	const int right = (last == gamma + 1) ? ~(int)(unsigned int)keys[gamma + 1] : gamma + 1;
+	nodes[(size_t)i * 4 + 3] = make_float4(__int_as_float(left), __int_as_float(right), 0.f, 0.f);
+	// parent links: (node << 1) | side
+	if (first == gamma) parent_leaf[gamma] = (i << 1); else parent_int[gamma] = (i << 1);
+	if (last == gamma + 1) parent_leaf[gamma + 1] = (i << 1) | 1; else parent_int[gamma + 1] = (i << 1) | 1;
+	if (i == 0) parent_int[0] = -1;
+}
+
+__device__ __forceinline__ void store_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float load_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// float offsets of child `side`'s box inside a node: lo xyz, hi xyz
+__device__ __forceinline__ void store_child_box(float* node, int side, const float lo[3], const float hi[3]) {
+	const int b = side * 6;
+#pragma unroll
+	for (int k = 0; k < 3; k++) { store_agent(node + b + k, lo[k]); store_agent(node + b + 3 + k, hi[k]); }
+}
+
+__global__ void __launch_bounds__(256) k_refit(const float4* __restrict__ planes, int stride, int n, const u64* __restrict__ keys,
+                                              float* __restrict__ nodes, const int* __restrict__ parent_int,
+                                              const int* __restrict__ parent_leaf, unsigned int* __restrict__ flags, float pad) {
+	const int p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= n) return;
+	const int tri = (int)(unsigned int)keys[p];
+	float lo[3], hi[3];
+	tri_box(planes, stride, tri, lo, hi);
+#pragma unroll
+	for (int k = 0; k < 3; k++) { lo[k] -= pad; hi[k] += pad; }
+	int link = parent_leaf[p];
+	// every lane's walk ends: at a node it reaches first, or at the root
+	for (int guard = 0; guard < 128 && link >= 0; guard++) {
+		const int node = link >> 1, side = link & 1;
+		float* nd = nodes + (size_t)node * 16;
+		store_child_box(nd, side, lo, hi);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		const unsigned int old = __hip_atomic_fetch_add(&flags[node], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (old == 0) return;                          // the sibling subtree is not done: its lane carries on
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+		const int ob = (side ^ 1) * 6;
+#pragma unroll
+		for (int k = 0; k < 3; k++) {
+			lo[k] = fminf(lo[k], load_agent(nd + ob + k));
+			hi[k] = fmaxf(hi[k], load_agent(nd + ob + 3 + k));
+		}
+		link = parent_int[node];
+	}
+}
+
+template <typename T>
+int dev_alloc(T** p, size_t count) {
+	hipError_t e = hipMalloc((void**)p, count * sizeof(T));
+	if (e != hipSuccess) return hip_fail(e, "hipMalloc (LBVH build)");
+	return RT_OK;
+}
+
+} // namespace
 
 void lbvh_free(DeviceState& d) {
 	if (d.bvh_nodes) (void)hipFree(d.bvh_nodes);
 	if (d.bvh_prim) (void)hipFree(d.bvh_prim);
 	d.bvh_nodes = nullptr;
 	d.bvh_prim = nullptr;
+}
+
+int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
+	const int n = (int)(s->tris.size() / RT_TRI_FLOATS);
+	if (n < 2) { set_error("LBVH needs at least two triangles"); return RT_ERR_LIMIT; }
+	for (int k = 0; k < 3; k++)
+		if (!(d.bb_hi[k] - d.bb_lo[k] < __builtin_huge_valf())) {
+			set_error("LBVH: the scene has a non-finite vertex; commit it with RT_ACCEL_BRUTE");
+			return RT_ERR_LIMIT;
+		}
+	lbvh_free(d);
+	u64 *keys = nullptr, *keys_sorted = nullptr;
+	int *parent_int = nullptr, *parent_leaf = nullptr;
+	unsigned int* flags = nullptr;
+	void* temp = nullptr;
+	float4* nodes = nullptr;
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	int rc = RT_OK;
+	auto cleanup = [&]() {
+		if (keys) (void)hipFree(keys);
+		if (keys_sorted) (void)hipFree(keys_sorted);
+		if (parent_int) (void)hipFree(parent_int);
+		if (parent_leaf) (void)hipFree(parent_leaf);
+		if (flags) (void)hipFree(flags);
+		if (temp) (void)hipFree(temp);
+		if (e0) (void)hipEventDestroy(e0);
+		if (e1) (void)hipEventDestroy(e1);
+	};
+#define LB_TRY(x) do { rc = (x); if (rc != RT_OK) { cleanup(); if (nodes) (void)hipFree(nodes); return rc; } } while (0)
+#define LB_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = hip_fail(e_, #x); cleanup(); if (nodes) (void)hipFree(nodes); return rc; } } while (0)
+	LB_TRY(dev_alloc(&keys, (size_t)n));
+	LB_TRY(dev_alloc(&keys_sorted, (size_t)n));
+	LB_TRY(dev_alloc(&parent_int, (size_t)n));
+	LB_TRY(dev_alloc(&parent_leaf, (size_t)n));
+	LB_TRY(dev_alloc(&flags, (size_t)n));
+	LB_TRY(dev_alloc(&nodes, (size_t)(n - 1) * 4));
+	size_t temp_bytes = 0;
+	LB_HIP(rocprim::radix_sort_keys(nullptr, temp_bytes, keys, keys_sorted, (size_t)n, 0, 62, stream));
+	LB_HIP(hipMalloc(&temp, temp_bytes > 0 ? temp_bytes : 16));
+	LB_HIP(hipEventCreate(&e0));
+	LB_HIP(hipEventCreate(&e1));
+
+	BoxF scene;
+	for (int k = 0; k < 3; k++) { scene.lo[k] = d.bb_lo[k]; scene.hi[k] = d.bb_hi[k]; }
+	const float pad = d.pad;
+	const float4* planes = (const float4*)d.planes;
+	const unsigned int blocks_n = (unsigned int)((n + 255) / 256);
+
+	LB_HIP(hipEventRecord(e0, stream));
+	LB_HIP(hipMemsetAsync(flags, 0, (size_t)n * sizeof(unsigned int), stream));
+	LB_HIP(hipMemsetAsync(nodes, 0, (size_t)(n - 1) * 4 * sizeof(float4), stream));
+	hipLaunchKernelGGL(k_morton, dim3(blocks_n), dim3(256), 0, stream, planes, d.stride, n, scene, keys);
+	LB_HIP(hipGetLastError());
+	LB_HIP(rocprim::radix_sort_keys(temp, temp_bytes, keys, keys_sorted, (size_t)n, 0, 62, stream));
+	hipLaunchKernelGGL(k_karras, dim3(blocks_n), dim3(256), 0, stream, keys_sorted, n, nodes, parent_int, parent_leaf);
+	LB_HIP(hipGetLastError());
+	hipLaunchKernelGGL(k_refit, dim3(blocks_n), dim3(256), 0, stream, planes, d.stride, n, keys_sorted, (float*)nodes,
+	                   parent_int, parent_leaf, flags, pad);
+	LB_HIP(hipGetLastError());
+	LB_HIP(hipEventRecord(e1, stream));
+	LB_HIP(hipEventSynchronize(e1));
+	float ms = 0.f;
+	LB_HIP(hipEventElapsedTime(&ms, e0, e1));
+	// the root must have been reached by exactly two arrivals
+	unsigned int root_flag = 0;
+	LB_HIP(hipMemcpy(&root_flag, flags, sizeof root_flag, hipMemcpyDeviceToHost));
+	if (root_flag != 2) {
+		set_error("LBVH refit did not reach the root (flag %u)", root_flag);
+		cleanup();
+		(void)hipFree(nodes);
+		return RT_ERR_DEVICE;
+	}
+#undef LB_TRY
+#undef LB_HIP
+	cleanup();
+	d.bvh_nodes = nodes;
+	d.bvh_root = 0;
+	d.build_ms = ms;
+	return RT_OK;
 }
 
 } // namespace rt
