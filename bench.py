@@ -134,7 +134,7 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     import torch
-    from raytracing_amd import api, scenes
+    from raytracing_amd import api, scenes, sharding
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the render loop has no CPU path")
@@ -159,20 +159,23 @@ def main():
 
     # work per pose (rays and algorithmic FLOPs), counted by the instrumented kernel outside the
     # timed region; identical to the oracle's counters (tests/test_gpu_parity.py)
-    my_frames = [(s * world + rank) % 64 for s in range(args.steps)]
+    tile_mode = args.workload == "sweep8k" and world > 1
+    if tile_mode:
+        my_frames = [s % 64 for s in range(args.steps)]         # every rank works on the same frame
+    else:
+        my_frames = sharding.frames_for_rank(args.steps, world, rank)
     need = sorted(set(my_frames))
     rays_of, flops_of = {}, {}
     for f in need:
         _, st = scene.render_stats(poses[f][0], trans[f], W, H, D, want_frame=False)
         rays_of[f], flops_of[f] = st.rays, st.flops
 
-    tile_mode = args.workload == "sweep8k" and world > 1
     if tile_mode:
         tile_rows = 16
         rows = api.shard_rows(H, tile_rows, rank, world)
         fb = torch.empty(rows * W * 3, dtype=torch.float32, device="cuda")
         full = torch.empty(H * W * 3, dtype=torch.float32, device="cuda") if rank == 0 else None
-        my_frames = [s % 64 for s in range(args.steps)]         # every rank works on the same frame
+        recv_bufs = [None] * world
     else:
         fb = torch.empty(H * W * 3, dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
@@ -192,11 +195,9 @@ def main():
             if rc != 0:
                 raise api.RtError(rc, L.rt_last_error().decode())
             return
-        if tile_mode:
-            scene.render_tiles_device(dev, poses[f][0], trans[f], W, H, D, mode, tile_rows, rank, world, fb.data_ptr(), stream)
-            gather_tiles(dist, fb, full, rank, world, H, W, tile_rows, api)
-        else:
-            scene.render_device(dev, poses[f][0], trans[f], W, H, D, mode, fb.data_ptr(), stream)
+        # row tiles: render this rank's interleaved tiles, then the one exchange step (RCCL)
+        scene.render_tiles_device(dev, poses[f][0], trans[f], W, H, D, mode, tile_rows, rank, world, fb.data_ptr(), stream)
+        sharding.gather_frame(dist, fb, full, rank, world, H, W, tile_rows, recv_bufs)
 
     for s in range(args.warmup):
         step(my_frames[s % len(my_frames)])
@@ -272,28 +273,6 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     scene.close()
-
-
-def gather_tiles(dist, fb, full, rank, world, H, W, tile_rows, api):
-    """Framebuffer gather to rank 0 (RCCL over xGMI): every rank sends its compact shard, rank 0
-    scatters the tiles to their rows.  One collective per frame."""
-    import torch
-    rows = [api.shard_rows(H, tile_rows, k, world) for k in range(world)]
-    if rank == 0:
-        parts = [torch.empty(r * W * 3, dtype=torch.float32, device="cuda") if k else fb for k, r in enumerate(rows)]
-        reqs = [dist.irecv(parts[k], src=k) for k in range(1, world)]
-        for q in reqs:
-            q.wait()
-        fv = full.view(H, W * 3)
-        for k in range(world):
-            pv = parts[k].view(rows[k], W * 3)
-            n_tiles = (rows[k] + tile_rows - 1) // tile_rows
-            for j in range(n_tiles):
-                t = k + j * world
-                r0, r1 = t * tile_rows, min((t + 1) * tile_rows, H)
-                fv[r0:r1] = pv[j * tile_rows: j * tile_rows + (r1 - r0)]
-    else:
-        dist.send(fb, dst=0)
 
 
 def read_traffic(workload):

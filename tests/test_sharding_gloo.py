@@ -1,0 +1,92 @@
+"""Multi-process path on CPU (gloo, world_size 2 and 3): the sharding/gather logic of
+raytracing_amd/sharding.py with the ORACLE standing in for the per-rank render (there is no GPU
+here; on the GPU box the same functions move rt_render_tiles_device output over RCCL).
+SURVEY.md §4 T5: the N-rank interleaved-row frame equals the 1-rank frame byte for byte."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+from raytracing_amd import sharding
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, height, width, tile_rows, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pyoracle
+    from raytracing_amd import scenes
+    desc = scenes.room(width, height)
+    tris, lights = pyoracle.build_scene(desc)
+    trans = pyoracle.camera_trans(desc.cam_rot)
+    # this rank's tiles, rendered by the checker, packed compactly like rt_render_tiles_device does
+    parts = []
+    for r0, r1 in sharding.shard_tiles(height, tile_rows, rank, world):
+        f = pyoracle.render(tris, lights, desc.cam_pos, trans, width, height, desc.depth, rows=(r0, r1, 1))
+        parts.append(f[r0:r1].reshape(-1))
+    shard = torch.from_numpy(np.concatenate(parts) if parts else np.zeros(0, np.float32))
+    assert shard.numel() == sharding.shard_rows(height, tile_rows, rank, world) * width * 3
+    full = torch.zeros(height * width * 3) if rank == 0 else None
+    dist.barrier()
+    got = sharding.gather_frame(dist, shard, full, rank, world, height, width, tile_rows)
+    # max-over-ranks timing reduction used by bench.py
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert t.item() == world
+    if rank == 0:
+        np.save(out_path, got.numpy().reshape(height, width, 3))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,height,width,tile_rows", [(2, 48, 40, 16), (2, 50, 24, 7), (3, 37, 16, 4)])
+def test_row_tile_gather_equals_single_rank(oracle, tmp_path, world, height, width, tile_rows):
+    from raytracing_amd import scenes
+    out_path = str(tmp_path / "frame.npy")
+    mp.spawn(_worker, args=(world, _free_port(), height, width, tile_rows, out_path), nprocs=world, join=True)
+    got = np.load(out_path)
+    want = oracle.render_desc(scenes.room(width, height))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_tile_partition_matches_c_abi():
+    from raytracing_amd import api
+    for h, tr, n in [(800, 16, 8), (4320, 16, 8), (100, 7, 3), (5, 16, 4)]:
+        rows = [sharding.shard_rows(h, tr, k, n) for k in range(n)]
+        assert rows == [api.shard_rows(h, tr, k, n) for k in range(n)]
+        covered = sorted(r for k in range(n) for t in sharding.shard_tiles(h, tr, k, n) for r in range(*t))
+        assert covered == list(range(h))
+
+
+def test_scatter_numpy_all_shapes():
+    rng = np.random.default_rng(0)
+    for h, w, tr, n in [(64, 5, 8, 4), (70, 3, 8, 4), (9, 2, 16, 2), (33, 4, 1, 5)]:
+        want = rng.random((h, w * 3)).astype(np.float32)
+        full = np.zeros(h * w * 3, np.float32)
+        for k in range(n):
+            tiles = sharding.shard_tiles(h, tr, k, n)
+            shard = np.concatenate([want[a:b].reshape(-1) for a, b in tiles]) if tiles else np.zeros(0, np.float32)
+            sharding.scatter_shard_into_frame(full, shard, h, w, tr, k, n)
+        assert np.array_equal(full.reshape(h, w * 3), want)
+
+
+def test_frames_round_robin():
+    a = sharding.frames_for_rank(5, 4, 1)
+    assert a == [1, 5, 9, 13, 17]
+    seen = sorted(f for r in range(8) for f in sharding.frames_for_rank(8, 8, r))
+    assert seen == list(range(64))
