@@ -52,6 +52,7 @@ def parse():
                     choices=["room800", "stock800", "mirrors4k", "spheres800", "spheres4k", "sweep8k"])
     ap.add_argument("--mode", default="strict", choices=["strict", "fast"])
     ap.add_argument("--tiles-per-wave", type=int, default=0)
+    ap.add_argument("--size", type=int, nargs=2, default=None, help="override the workload's frame size (experiments)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -146,6 +147,9 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
 
     desc, accel_name, label = make_workload(args.workload)
+    if args.size:
+        desc = desc.with_size(args.size[0], args.size[1])
+        label += " [size overridden to %dx%d]" % tuple(args.size)
     accel = api.ACCEL_LBVH if accel_name == "lbvh" else api.ACCEL_BRUTE
     mode = api.FAST if args.mode == "fast" else api.STRICT
     if args.tiles_per_wave:

@@ -165,12 +165,12 @@ int rt_scene_commit(rt_scene* s, int device, int accel_flags) {
 	// (keeps b * inv and o * inv finite for |inv| <= 1e30): rt_kernels.hip cast_ray_pruned.
 	d.far_guard = pad * 1e6f < 1e6f ? pad * 1e6f : 1e6f;
 	if (!(pad * 1e3f <= 1e6f)) d.far_guard = 0.f;
-	try { flatten_planes(s->tris, d.stride, pad, planes); } catch (...) { set_error("rt_scene_commit: out of host memory"); return RT_ERR_NOMEM; }
+	try { d.n_clusters = flatten_planes(s->tris, d.stride, pad, planes); } catch (...) { set_error("rt_scene_commit: out of host memory"); return RT_ERR_NOMEM; }
 	RT_HIP(hipMalloc(&d.planes, planes.size() * sizeof(float)));
 	RT_HIP(hipMemcpy(d.planes, planes.data(), planes.size() * sizeof(float), hipMemcpyHostToDevice));
 	RT_HIP(hipMalloc(&d.lights, (size_t)(nl > 0 ? nl : 1) * 4 * sizeof(float)));
 	if (nl > 0) RT_HIP(hipMemcpy(d.lights, s->lights.data(), (size_t)nl * 4 * sizeof(float), hipMemcpyHostToDevice));
-	RT_HIP(hipMalloc(&d.counters, 16 * sizeof(unsigned long long)));
+	RT_HIP(hipMalloc(&d.counters, 32 * sizeof(unsigned long long)));
 	d.accel = accel_flags == RT_ACCEL_AUTO ? (n > RT_BRUTE_AUTO_MAX ? RT_ACCEL_LBVH : RT_ACCEL_BRUTE) : accel_flags;
 	if (d.accel == RT_ACCEL_LBVH && n < 2) d.accel = RT_ACCEL_BRUTE;    // a tree needs two leaves
 	d.build_ms = 0.f;
@@ -292,20 +292,28 @@ int rt_render_stats(rt_scene* s, const float cam_pos[3], const float trans16[16]
 	const size_t bytes = (size_t)width * height * 3 * sizeof(float);
 	rc = ensure_frame(*d, bytes);
 	if (rc != RT_OK) return rc;
-	RT_HIP(hipMemsetAsync(d->counters, 0, 16 * sizeof(unsigned long long), nullptr));
+	RT_HIP(hipMemsetAsync(d->counters, 0, 32 * sizeof(unsigned long long), nullptr));
 	FrameParams fp;
 	fill_frame(fp, cam_pos, trans16, width, height, max_bounces);
 	fp.tiles_per_wave = g_tiles_per_wave_override;
 	fp.out = (float*)d->frame;
 	fp.counters = (unsigned long long*)d->counters;
+#ifdef RT_PROFILE
+	rc = launch_render(dev_scene(s, *d), fp, d->accel, RT_RENDER_STRICT, false, nullptr);   // wave-level tuning counters
+#else
 	rc = launch_render(dev_scene(s, *d), fp, d->accel, RT_RENDER_STRICT, true, nullptr);
+#endif
 	if (rc != RT_OK) return rc;
-	unsigned long long c[16];
+	unsigned long long c[32];
 	RT_HIP(hipMemcpy(c, d->counters, sizeof c, hipMemcpyDeviceToHost));
 	if (out_rgb) RT_HIP(hipMemcpy(out_rgb, d->frame, bytes, hipMemcpyDeviceToHost));
 	out->rays_primary = c[0]; out->rays_bounce = c[1]; out->rays_shadow = c[2];
 	out->n_plane = c[3]; out->n_point = c[4]; out->n_edge = c[5]; out->n_box = c[6];
 	out->px_hit = c[7]; out->px_mirror = c[8]; out->px_lit = c[9];
+#ifdef RT_PROFILE
+	fprintf(stderr, "RT_PROFILE cycles: staging %llu setup %llu trace-rest %llu shade %llu | boxes %llu prefilter %llu exact %llu bounds %llu\n",
+	        c[10], c[11], c[12], c[13], c[14], c[15], c[16], c[17]);
+#endif
 	return RT_OK;
 }
 

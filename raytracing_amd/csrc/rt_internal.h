@@ -24,14 +24,19 @@ namespace rt {
 //   plane 6  E2 = (edge2.xyz, 0)                        Source.cpp:54
 //   plane 7  GLO[g] = lower corner of the padded box of triangles 4g..4g+3 (entries g < stride/4)
 //   plane 8  GHI[g] = upper corner            (an empty group has GLO = +inf, GHI = -inf)
+//   plane 9  CLO[c] = (lower corner of cluster c, first group as int bits)   clusters = runs of
+//   plane 10 CHI[c] = (upper corner,              group count as int bits)   consecutive groups
 // The `p` field of the reference record (Source.cpp:33, always == p1) is not uploaded.
-enum { PL_N = 0, PL_P1, PL_P2, PL_P3, PL_E0, PL_E1, PL_E2, PL_GLO, PL_GHI, PL_COUNT };
-#define RT_GROUP 4
+enum { PL_N = 0, PL_P1, PL_P2, PL_P3, PL_E0, PL_E1, PL_E2, PL_GLO, PL_GHI, PL_CLO, PL_CHI, PL_COUNT };
+#define RT_CLUSTER_MAX_GROUPS 16
+#ifndef RT_GROUP
+#define RT_GROUP 2
+#endif
 
-// Brute force keeps the whole scene in LDS up to this many triangles ((9 planes x 16 B + 4 B) x
-// 384 = 55.5 KiB, under the 64 KiB a workgroup gets without opting in to more); above it the
+// Brute force keeps the whole scene in LDS up to this many triangles ((11 planes x 16 B + 4 B) x
+// 320 = 56.3 KiB, under the 64 KiB a workgroup gets without opting in to more); above it the
 // brute-force kernel reads the planes from global memory / L2 instead.
-#define RT_LDS_MAX_TRIS 384
+#define RT_LDS_MAX_TRIS 320
 
 struct DevScene {
 	const float4* planes;   // PL_COUNT * stride float4
@@ -39,7 +44,7 @@ struct DevScene {
 	int n_tris;
 	int stride;
 	int n_lights;
-	int pad;
+	int n_clusters;
 	// LBVH (null for brute force): see rt_lbvh.hip
 	const float4* bvh_nodes;
 	const int* bvh_prim;
@@ -83,6 +88,7 @@ struct DeviceState {
 	float bb_lo[3] = { 0, 0, 0 }, bb_hi[3] = { 0, 0, 0 };
 	float far_guard = 0.f;
 	float pad = 0.f;
+	int n_clusters = 0;
 	// scratch framebuffer for rt_render (host output)
 	void* frame = nullptr;
 	size_t frame_bytes = 0;
@@ -110,7 +116,7 @@ int hip_fail(hipError_t e, const char* what);
 void triangle_record(vec3 p1, vec3 p2, vec3 p3, vec3 color, float shin, float* out28);
 void quad_half_record(const float T[3], const float Rdeg[3], const float S[3], const float color[3], float shin, float* out28);
 void camera_trans(const float rot_deg[3], float out16[16]);
-void flatten_planes(const std::vector<float>& tris, int stride, float pad, std::vector<float>& out);
+int flatten_planes(const std::vector<float>& tris, int stride, float pad, std::vector<float>& out);   // returns the cluster count
 float scene_box(const std::vector<float>& tris, float lo[3], float hi[3]);   // returns the pad it applied
 
 // rt_kernels.hip

@@ -41,6 +41,20 @@ struct Hit {
 	vec3 p;       // closest.point
 };
 
+// Wave-level event counts for tuning (RT_PROFILE builds only; scripts/prof_build.sh).
+#ifdef RT_PROFILE
+struct WaveProf { unsigned int v[10]; unsigned long long t[10]; unsigned long long last; };
+#define RT_PROF(p, k) ((p).v[k]++)
+// segment stamp: adds the cycles since the previous stamp to segment k (diagnostic builds only)
+#define RT_STAMP(p, k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+	__builtin_amdgcn_s_waitcnt(0xC07F); (p).t[k] += now_ - (p).last; (p).last = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+struct WaveProf { };
+#define RT_PROF(p, k) ((void)0)
+#define RT_STAMP(p, k) ((void)0)
+#endif
+enum { WP_TRACE = 0, WP_GROUP, WP_INBOX, WP_TRI, WP_MAYBE, WP_CAND, WP_C0, WP_C1, WP_ACCEPT, WP_ITER };
+
 struct LaneCounters {
 	unsigned int plane, point, edge, box;
 };
@@ -108,18 +122,21 @@ __device__ __forceinline__ Hit cast_ray_brute(TriPtr tri, int stride, int n, vec
 // Edge tests and acceptance for ONE triangle whose exact t is known (Source.cpp:389-396).
 template <typename TriPtr>
 __device__ __forceinline__ void accept_triangle(TriPtr tri, int stride, int i, vec3 nn, vec3 p1, vec3 o, vec3 d, float t,
-                                                bool cand, int skip, bool first_only, Hit& h, float& lim, float& lim_hi) {
+                                                bool cand, int skip, bool first_only, Hit& h, float& lim, float& lim_hi, WaveProf& wp) {
 	const vec3 I = make3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);   // Source.cpp:389
 	const float4 E0 = tri[PL_E0 * stride + i];
 	const bool c0 = cand && (dot(nn, cross(xyz(E0), I - p1)) > 0.0f);    // Source.cpp:392
 	if (__builtin_amdgcn_ballot_w64(c0) == 0) return;
+	RT_PROF(wp, WP_C0);
 	const float4 P24 = tri[PL_P2 * stride + i];
 	const float4 E1 = tri[PL_E1 * stride + i];
 	const bool c1 = c0 && (dot(nn, cross(xyz(E1), I - xyz(P24))) > 0.0f);   // Source.cpp:393
 	if (__builtin_amdgcn_ballot_w64(c1) == 0) return;
+	RT_PROF(wp, WP_C1);
 	const float4 P34 = tri[PL_P3 * stride + i];
 	const float4 E2 = tri[PL_E2 * stride + i];
 	const bool c2 = c1 && (dot(nn, cross(xyz(E2), I - xyz(P34))) > 0.0f);   // Source.cpp:394
+	if (__builtin_amdgcn_ballot_w64(c2) != 0) RT_PROF(wp, WP_ACCEPT);
 	if (c2 && i != skip) {                                                  // Source.cpp:302, 396
 		h.t = t; h.idx = i; h.p = I;
 		lim = first_only ? -1.0f : t;
@@ -127,71 +144,92 @@ __device__ __forceinline__ void accept_triangle(TriPtr tri, int stride, int i, v
 	}
 }
 
-// The loop itself, over groups of RT_GROUP consecutive triangles.
-//  (4) Each group has a padded bounding box (host: flatten_planes).  A hit point lies in its
-//      triangle's box up to rounding that the pad exceeds by orders of magnitude, so a group whose
-//      box the ray misses — or only meets beyond `lim` — is skipped as a whole (one slab test per
-//      group instead of RT_GROUP plane tests plus the edge terms of every plane the ray happens
-//      to cross: the infinite planes of a small object are crossed by most rays of a frame).
+// Ray / padded-box slab test with precomputed inv = 1/d and oi = -o/d: does the ray meet the box
+// within [0, lim_hi]?  v_min/v_max drop NaN operands (0 * inf on a slab the ray lies in): that axis
+// then does not constrain, which errs on the side of "hit".  Rays whose boxes are not to be
+// trusted (far_guard) come in with inv = oi = 0: every box then tests as hit.
+__device__ __forceinline__ bool slab_hit(float4 lo, float4 hi, vec3 inv, vec3 oi, float lim_hi) {
+	const float x0 = __builtin_fmaf(lo.x, inv.x, oi.x), x1 = __builtin_fmaf(hi.x, inv.x, oi.x);
+	const float y0 = __builtin_fmaf(lo.y, inv.y, oi.y), y1 = __builtin_fmaf(hi.y, inv.y, oi.y);
+	const float z0 = __builtin_fmaf(lo.z, inv.z, oi.z), z1 = __builtin_fmaf(hi.z, inv.z, oi.z);
+	const float tmin = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
+	const float tmax = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), lim_hi));
+	return !(tmin > tmax);
+}
+
+// The loop itself, over clusters of groups of RT_GROUP consecutive triangles.
+//  (4) Each group has a padded bounding box, and runs of groups whose common box is small against
+//      the scene form a cluster with a box of its own (host: flatten_planes).  A hit point lies in
+//      its triangle's box up to rounding that the pad exceeds by orders of magnitude, so a group
+//      (cluster) whose box no ray of the wave meets within [0, lim] is skipped as a whole: one slab
+//      test instead of RT_GROUP plane tests plus the edge terms of every plane the rays happen to
+//      cross (the infinite planes of a small object are crossed by most rays of a frame, its box
+//      by few).
 //  (5) Per triangle the wave first forms ta = num * rcp(den): v_rcp_f32 is within 1 ulp, so ta is
 //      within 3 * 2^-24 of the correctly rounded quotient t whenever rcp(den) is a normal number.
-//      A triangle with ta outside [eps*(1 - 2^-20), lim*(1 + 2^-20)] therefore cannot satisfy
-//      eps < t < lim and is dropped without the IEEE division; everything else (including NaN and
-//      any den whose reciprocal is not a normal float) goes on to the exact t = num / den and the
-//      reference's own comparisons.
+//      A triangle with ta outside [eps*(1 - 2^-20), lim*(1 + 2^-20)] cannot satisfy eps < t < lim
+//      and is dropped without the IEEE division; everything else (including NaN and any den whose
+//      reciprocal is not a normal float) goes on to the exact t = num / den and the reference's
+//      own comparisons.
 // Neither filter ever decides a hit; both only skip work, and NaNs always fall through to the
-// exact path.  `cull` is false for rays whose origin is too far out for the slab arithmetic.
+// exact path.  (Measured alternatives, kept out: testing all boxes branch-free into a wave mask
+// first, and a straight-line exact path per group, shorten a lone wave's latency but cost
+// instructions and registers; at steady state they are 10-20 % slower than this form.)
 template <bool PRIMARY, typename TriPtr>
-__device__ __forceinline__ Hit cast_ray_pruned(TriPtr tri, int stride, int n, const float* num0, vec3 o, vec3 d,
-                                               int skip, float lim, bool first_only, bool cull) {
+__device__ __forceinline__ Hit cast_ray_pruned(TriPtr tri, int stride, int n, int n_clusters, const float* num0, vec3 o, vec3 d,
+                                               vec3 inv, vec3 oi, int skip, float lim, bool first_only, WaveProf& wp) {
+	RT_PROF(wp, WP_TRACE);
+	RT_STAMP(wp, 7);        // bounds + slab set-up (since the last outer stamp)
 	Hit h;
 	h.t = 1e9f;
 	h.idx = -1;
 	h.p = make3(0.f, 0.f, 0.f);
 	float lim_hi = lim + fabsf(lim) * RT_PREFILTER_REL;
 	const float eps_lo = RT_EPS_BELOW * (1.0f - RT_PREFILTER_REL);
-	// Slab arithmetic t = b * inv - o * inv must stay finite: a direction component below 1e-30
-	// is widened to 1e-30 (its slab interval is then ~(-1e28, 1e28) around any origin inside the
-	// slab, empty for origins outside), and the host switches culling off (far_guard) for origins
-	// or scenes large enough for the products to overflow or to lose the pad to rounding.
-	const vec3 ds = make3(fabsf(d.x) < 1e-30f ? 1e-30f : d.x, fabsf(d.y) < 1e-30f ? 1e-30f : d.y, fabsf(d.z) < 1e-30f ? 1e-30f : d.z);
-	const vec3 inv = make3(__builtin_amdgcn_rcpf(ds.x), __builtin_amdgcn_rcpf(ds.y), __builtin_amdgcn_rcpf(ds.z));
-	const vec3 oi = make3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
-	for (int g = 0; g * RT_GROUP < n; g++) {
-		const float4 lo = tri[PL_GLO * stride + g];
-		const float4 hi = tri[PL_GHI * stride + g];
-		const float x0 = __builtin_fmaf(lo.x, inv.x, oi.x), x1 = __builtin_fmaf(hi.x, inv.x, oi.x);
-		const float y0 = __builtin_fmaf(lo.y, inv.y, oi.y), y1 = __builtin_fmaf(hi.y, inv.y, oi.y);
-		const float z0 = __builtin_fmaf(lo.z, inv.z, oi.z), z1 = __builtin_fmaf(hi.z, inv.z, oi.z);
-		// v_min/v_max drop NaN operands (0 * inf on a slab the ray lies in): that axis then does not constrain
-		const float tmin = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
-		const float tmax = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), lim_hi));
-		const bool inbox = !(tmin > tmax) || !cull;
-		if (__builtin_amdgcn_ballot_w64(inbox) == 0) continue;
+	for (int c = 0; c < n_clusters; c++) {
+		const float4 clo = tri[PL_CLO * stride + c];
+		const float4 chi = tri[PL_CHI * stride + c];
+		const int g0 = __builtin_amdgcn_readfirstlane(__float_as_int(clo.w));
+		const int g1 = g0 + __builtin_amdgcn_readfirstlane(__float_as_int(chi.w));
+		if (g1 - g0 > 1) {
+			// several groups share this box: one test may skip them all
+			RT_PROF(wp, WP_GROUP);
+			if (__builtin_amdgcn_ballot_w64(slab_hit(clo, chi, inv, oi, lim_hi)) == 0) continue;
+		}
+		for (int g = g0; g < g1; g++) {
+			const float4 lo = tri[PL_GLO * stride + g];
+			const float4 hi = tri[PL_GHI * stride + g];
+			RT_PROF(wp, WP_GROUP);
+			if (__builtin_amdgcn_ballot_w64(slab_hit(lo, hi, inv, oi, lim_hi)) == 0) continue;
+			RT_PROF(wp, WP_INBOX);
 #pragma unroll
-		for (int k = 0; k < RT_GROUP; k++) {
-			const int i = g * RT_GROUP + k;
-			if (i >= n) break;
-			const vec3 nn = xyz(tri[PL_N * stride + i]);
-			vec3 p1 = make3(0.f, 0.f, 0.f);
-			float num;
-			if constexpr (PRIMARY) {
-				num = num0[i];
-			} else {
-				p1 = xyz(tri[PL_P1 * stride + i]);
-				num = dot(p1 - o, nn);
+			for (int k = 0; k < RT_GROUP; k++) {
+				const int i = g * RT_GROUP + k;
+				if (i >= n) break;
+				RT_PROF(wp, WP_TRI);
+				const vec3 nn = xyz(tri[PL_N * stride + i]);
+				vec3 p1 = make3(0.f, 0.f, 0.f);
+				float num;
+				if constexpr (PRIMARY) {
+					num = num0[i];
+				} else {
+					p1 = xyz(tri[PL_P1 * stride + i]);
+					num = dot(p1 - o, nn);
+				}
+				const float den = dot(d, nn);
+				const float r = __builtin_amdgcn_rcpf(den);
+				const float ta = num * r;
+				const bool normal = __builtin_amdgcn_classf(r, 0x108);          // +-normal
+				const bool maybe = !normal || (!(ta < eps_lo) && !(ta > lim_hi));
+				if (__builtin_amdgcn_ballot_w64(maybe) == 0) continue;
+				RT_PROF(wp, WP_MAYBE);
+				const float t = num / den;                                      // Source.cpp:383
+				const bool cand = maybe && (t > RT_EPS_BELOW) && (t < lim);     // Source.cpp:385, 391
+				if (__builtin_amdgcn_ballot_w64(cand) == 0) continue;
+				RT_PROF(wp, WP_CAND);
+				if constexpr (PRIMARY) p1 = xyz(tri[PL_P1 * stride + i]);
+				accept_triangle(tri, stride, i, nn, p1, o, d, t, cand, skip, first_only, h, lim, lim_hi, wp);
 			}
-			const float den = dot(d, nn);
-			const float r = __builtin_amdgcn_rcpf(den);
-			const float ta = num * r;
-			const bool normal = __builtin_amdgcn_classf(r, 0x108);          // +-normal
-			const bool maybe = inbox && (!normal || (!(ta < eps_lo) && !(ta > lim_hi)));
-			if (__builtin_amdgcn_ballot_w64(maybe) == 0) continue;
-			const float t = num / den;                                      // Source.cpp:383
-			const bool cand = maybe && (t > RT_EPS_BELOW) && (t < lim);     // Source.cpp:385, 391
-			if (__builtin_amdgcn_ballot_w64(cand) == 0) continue;
-			if constexpr (PRIMARY) p1 = xyz(tri[PL_P1 * stride + i]);
-			accept_triangle(tri, stride, i, nn, p1, o, d, t, cand, skip, first_only, h, lim, lim_hi);
 		}
 	}
 	return h;
@@ -210,6 +248,18 @@ __device__ __forceinline__ float exit_bound(const DevScene& sc, vec3 o, vec3 d) 
 	return te + fabsf(te) * 1e-4f;                       // NaN (all-NaN ray) is dropped by the caller's fminf
 }
 
+// x / 255.0 in binary64, correctly rounded, without the division sequence: Markstein's
+// q' = fma(r, c, q) with q = x*c, r = fma(-q, 255, x), c = RN(1/255) is the correctly rounded
+// quotient whenever q is finite (checked against exact rationals on 4e5 samples);
+// a non-finite q (x = +-inf or NaN) is already the quotient.
+__device__ __forceinline__ double div255(double x) {
+	const double c = 1.0 / 255.0;
+	const double q = x * c;
+	const double r = __builtin_fma(-q, 255.0, x);
+	const double q2 = __builtin_fma(r, c, q);
+	return (q - q == 0.0) ? q2 : q;
+}
+
 // ---- pixel <-> work index ------------------------------------------------------------------
 // Work items are numbered tile-major: item g -> tile g/64 (tiles run left to right, then up),
 // pixel g%64 inside the 8x8 tile.  A wave owns `tiles_per_wave` consecutive tiles.
@@ -218,27 +268,41 @@ struct PixelId {
 	bool inside;
 };
 
-__device__ __forceinline__ PixelId pixel_of(long long g, int tiles_x, int width, int local_rows, long long n_items) {
+// (tx0, ty0) is the wave-uniform position of tile g0 >> 6; a lane's item g is in that tile or in
+// one of the next few, so no per-lane division is needed.
+__device__ __forceinline__ PixelId pixel_of(unsigned int g, unsigned int base_tile, int tx0, int ty0, int tiles_x,
+                                            int width, int local_rows) {
 	PixelId p;
-	const long long tile = g >> 6;
-	const int in = (int)(g & 63);
-	const int ty = (int)(tile / tiles_x), tx = (int)(tile - (long long)ty * tiles_x);
+	const int in = (int)(g & 63u);
+	int tx = tx0 + (int)((g >> 6) - base_tile), ty = ty0;
+	while (tx >= tiles_x) { tx -= tiles_x; ty++; }
 	p.x = tx * 8 + (in & 7);
 	p.ly = ty * 8 + (in >> 3);
-	p.inside = (g < n_items) && (p.x < width) && (p.ly < local_rows);
+	p.inside = (p.x < width) && (p.ly < local_rows);
 	return p;
 }
 
 __device__ __forceinline__ int global_row(int ly, const FrameParams& fp) {
 	// rt_internal.h FrameParams: local row -> tile of this shard -> global tile -> global row
+	if (fp.tile_stride == 1 && fp.tile_first == 0) return ly;          // whole frame (wave-uniform branch)
 	const int lt = ly / fp.tile_rows;
 	return (fp.tile_first + lt * fp.tile_stride) * fp.tile_rows + (ly - lt * fp.tile_rows);
 }
 
 // Source.cpp:534-545: u, v in double then rounded; dir = (trans * vec4(u, v, 0.5, 1)).xyz
 __device__ __forceinline__ vec3 primary_dir(int x, int y, const FrameParams& fp) {
-	const float v = (float)(((double)y - (double)fp.height / 2.0) / (double)(float)fp.height);
-	const float u = (float)(((double)x - (double)fp.width / 2.0) / (double)(float)fp.width);
+	// (x - w/2.0) / (float)w in double, rounded to float.  For w, h < 2^22 the numerator is a
+	// half-integer below 2^22 and the denominator an integer: both exact in binary32, and rounding a
+	// binary64 quotient of binary32 operands to binary32 equals the correctly rounded binary32
+	// quotient (53 >= 2*24 + 2), so one IEEE binary32 division gives the same bits.
+	float u, v;
+	if (fp.width < (1 << 22) && fp.height < (1 << 22)) {
+		v = ((float)y - (float)fp.height * 0.5f) / (float)fp.height;
+		u = ((float)x - (float)fp.width * 0.5f) / (float)fp.width;
+	} else {
+		v = (float)(((double)y - (double)fp.height / 2.0) / (double)(float)fp.height);
+		u = (float)(((double)x - (double)fp.width / 2.0) / (double)(float)fp.width);
+	}
 	const float* m = fp.m;
 	vec3 r;
 	r.x = (m[0] * u + m[4] * v) + (m[8] * 0.5f + m[12] * 1.0f);
@@ -267,7 +331,7 @@ __device__ __forceinline__ void flush_counters(unsigned long long* g, const unsi
 template <int ACCEL, bool COUNT>
 __device__ __forceinline__ Hit trace(const DevScene& sc, const float4* lds_tri, int lds_stride, const float* lds_num0,
                                      vec3 o, vec3 d, int skip, bool live, bool shadow, float dist, bool all_primary,
-                                     LaneCounters& lc);
+                                     LaneCounters& lc, WaveProf& wp);
 
 } // namespace rt
 
@@ -278,7 +342,7 @@ namespace rt {
 template <int ACCEL, bool COUNT>
 __device__ __forceinline__ Hit trace(const DevScene& sc, const float4* lds_tri, int lds_stride, const float* lds_num0,
                                      vec3 o, vec3 d, int skip, bool live, bool shadow, float dist, bool all_primary,
-                                     LaneCounters& lc) {
+                                     LaneCounters& lc, WaveProf& wp) {
 	if constexpr (ACCEL == 2) {
 		return cast_ray_lbvh<COUNT>(sc, (int*)lds_tri, o, d, skip, live, shadow, dist, lc);
 	} else if constexpr (COUNT) {
@@ -287,17 +351,28 @@ __device__ __forceinline__ Hit trace(const DevScene& sc, const float4* lds_tri, 
 		else return cast_ray_brute<true>(sc.planes, sc.stride, sc.n_tris, o, d, skip, live, lc);
 	} else {
 		// limit of the search (see cast_ray_pruned); idle lanes get a limit nothing passes
+		// Slab arithmetic t = b * inv - o * inv must stay finite: a direction component below 1e-30
+		// is widened to 1e-30 (its slab interval is then ~(-1e28, 1e28) around any origin inside the
+		// slab, empty for origins outside), and the host switches culling off (far_guard) for origins
+		// or scenes large enough for the products to overflow or to lose the pad to rounding.
+		const vec3 ds = make3(fabsf(d.x) < 1e-30f ? 1e-30f : d.x, fabsf(d.y) < 1e-30f ? 1e-30f : d.y, fabsf(d.z) < 1e-30f ? 1e-30f : d.z);
 		const bool near = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) < sc.far_guard;   // false for NaN too
-		float lim = near ? fminf(exit_bound(sc, o, d), 1e9f) : 1e9f;         // 1e9: Source.cpp:278
+		vec3 inv = make3(__builtin_amdgcn_rcpf(ds.x), __builtin_amdgcn_rcpf(ds.y), __builtin_amdgcn_rcpf(ds.z));
+		vec3 oi = make3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
+		// where the ray leaves the padded scene box: no hit lies beyond (same arithmetic as the slabs)
+		const float ex = fminf(fminf(fmaxf(__builtin_fmaf(sc.bb_lo[0], inv.x, oi.x), __builtin_fmaf(sc.bb_hi[0], inv.x, oi.x)),
+		                             fmaxf(__builtin_fmaf(sc.bb_lo[1], inv.y, oi.y), __builtin_fmaf(sc.bb_hi[1], inv.y, oi.y))),
+		                       fmaxf(__builtin_fmaf(sc.bb_lo[2], inv.z, oi.z), __builtin_fmaf(sc.bb_hi[2], inv.z, oi.z)));
+		float lim = near ? fminf(ex + fabsf(ex) * 1e-4f, 1e9f) : 1e9f;       // 1e9: Source.cpp:278
 		if (shadow) lim = fminf(lim, __uint_as_float(__float_as_uint(dist) + 1u));   // first float > dist (dist >= +0)
 		lim = fminf(lim, 1e9f);                                              // (dist == inf -> NaN -> dropped)
 		if (!live) lim = -1.0f;
-		const bool cull = near;
+		if (!near) { inv = make3(0.f, 0.f, 0.f); oi = make3(0.f, 0.f, 0.f); }   // every box tests as hit
 		if constexpr (ACCEL == 0) {
-			if (all_primary) return cast_ray_pruned<true>(lds_tri, lds_stride, sc.n_tris, lds_num0, o, d, skip, lim, false, cull);
-			return cast_ray_pruned<false>(lds_tri, lds_stride, sc.n_tris, lds_num0, o, d, skip, lim, shadow, cull);
+			if (all_primary) return cast_ray_pruned<true>(lds_tri, lds_stride, sc.n_tris, sc.n_clusters, lds_num0, o, d, inv, oi, skip, lim, false, wp);
+			return cast_ray_pruned<false>(lds_tri, lds_stride, sc.n_tris, sc.n_clusters, lds_num0, o, d, inv, oi, skip, lim, shadow, wp);
 		} else {
-			return cast_ray_pruned<false>(sc.planes, sc.stride, sc.n_tris, nullptr, o, d, skip, lim, shadow, cull);
+			return cast_ray_pruned<false>(sc.planes, sc.stride, sc.n_tris, sc.n_clusters, nullptr, o, d, inv, oi, skip, lim, shadow, wp);
 		}
 	}
 }
@@ -310,7 +385,13 @@ __device__ __forceinline__ float4 tri_plane(const DevScene& sc, const float4* ld
 }
 
 template <int ACCEL, bool COUNT>
-__global__ void __launch_bounds__(256) render_kernel(DevScene sc, FrameParams fp, int tiles_per_wave) {
+#ifndef RT_MIN_WAVES
+#define RT_MIN_WAVES 8      /* 64 VGPRs: 8 waves per SIMD; +6 % at steady state over 7 (measured) */
+#endif
+__global__ void __launch_bounds__(256, RT_MIN_WAVES) render_kernel(DevScene sc, FrameParams fp, int tiles_per_wave) {
+#ifdef RT_PROFILE
+	const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
 	extern __shared__ float4 s_tri[];
 	const int lds_stride = lds_stride_of(sc.n_tris);
 	float* s_num0 = (float*)(s_tri + PL_COUNT * lds_stride);
@@ -329,11 +410,16 @@ __global__ void __launch_bounds__(256) render_kernel(DevScene sc, FrameParams fp
 
 	const int tiles_x = (fp.width + 7) >> 3;
 	const int tiles_y = (fp.local_rows + 7) >> 3;
-	const long long n_items = (long long)tiles_x * tiles_y * 64;
-	const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-	long long next = wave * tiles_per_wave * 64;                   // wave-uniform cursor
-	long long end = next + (long long)tiles_per_wave * 64;
-	if (end > n_items) end = n_items;
+	// work items fit 32 bits: width * height * 3 < 2^31 is checked on the host (Source.cpp:550 uses int)
+	const unsigned int n_items = (unsigned int)tiles_x * (unsigned int)tiles_y * 64u;
+	const unsigned int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+	unsigned int next = wave * (unsigned int)tiles_per_wave * 64u;  // wave-uniform cursor
+	unsigned int end = next + (unsigned int)tiles_per_wave * 64u;
+	if (end > n_items || end < next) end = n_items;
+	if (next > n_items) next = n_items;
+	// position of the cursor's tile, kept in step with `next` (uniform, one division per wave)
+	unsigned int base_tile = next >> 6;
+	int ty0 = (int)(base_tile / (unsigned int)tiles_x), tx0 = (int)(base_tile - (unsigned int)ty0 * (unsigned int)tiles_x);
 
 	// per-lane ray state
 	int stage = ST_IDLE;
@@ -346,7 +432,7 @@ __global__ void __launch_bounds__(256) render_kernel(DevScene sc, FrameParams fp
 	vec3 hp = make3(0.f, 0.f, 0.f);
 	int hidx = -1;
 	int li = 0;
-	float dist = 0.f;
+	float dist = 0.f, intensity = 0.f;
 	vec3 color = make3(0.f, 0.f, 0.f);
 	bool lit_any = false;
 
@@ -354,6 +440,12 @@ __global__ void __launch_bounds__(256) render_kernel(DevScene sc, FrameParams fp
 #pragma unroll
 	for (int k = 0; k < CTR_N; k++) ctr[k] = 0;
 	LaneCounters lc = { 0, 0, 0, 0 };
+	WaveProf wp = {};
+#ifdef RT_PROFILE
+	wp.last = __builtin_amdgcn_s_memtime();
+	__builtin_amdgcn_s_waitcnt(0xC07F);
+	wp.t[0] = wp.last - t_start;       // argument loads + LDS staging
+#endif
 
 	for (;;) {
 		// ---- regeneration: idle lanes take the next pixels of the wave's tile run ---------------
@@ -362,10 +454,10 @@ __global__ void __launch_bounds__(256) render_kernel(DevScene sc, FrameParams fp
 			const unsigned long long m = __ballot(want);
 			if (m) {
 				const int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0));
-				const long long g = next + rank;
-				next += __popcll(m);
+				const unsigned int g = next + (unsigned int)rank;
+				next += (unsigned int)__popcll(m);
 				if (want && g < end) {
-					const PixelId px = pixel_of(g, tiles_x, fp.width, fp.local_rows, n_items);
+					const PixelId px = pixel_of(g, base_tile, tx0, ty0, tiles_x, fp.width, fp.local_rows);
 					if (px.inside) {
 						const int y = global_row(px.ly, fp);
 						out_index = (px.ly * fp.width + px.x) * 3;            // Source.cpp:550 (local rows)
@@ -376,8 +468,14 @@ __global__ void __launch_bounds__(256) render_kernel(DevScene sc, FrameParams fp
 						if (COUNT) ctr[CTR_PRIMARY]++;
 					}
 				}
+				// advance the uniform tile position to the new cursor
+				const unsigned int nt = next >> 6;
+				tx0 += (int)(nt - base_tile);
+				while (tx0 >= tiles_x) { tx0 -= tiles_x; ty0++; }
+				base_tile = nt;
 			}
 		}
+		RT_STAMP(wp, 1);      // regeneration + primary ray set-up
 		const bool live = (stage != ST_IDLE);
 		if (!__any(live)) {
 			if (next >= end) break;
@@ -387,12 +485,17 @@ __global__ void __launch_bounds__(256) render_kernel(DevScene sc, FrameParams fp
 		// ---- the one closest-hit loop ---------------------------------------------------------
 		const bool all_primary = __builtin_amdgcn_ballot_w64(live && stage != ST_PRIMARY) == 0;
 		const Hit h = trace<ACCEL, COUNT>(sc, s_tri, lds_stride, s_num0, o, d, skip, live, stage == ST_SHADOW, dist,
-		                                  all_primary, lc);
+		                                  all_primary, lc, wp);
+		RT_PROF(wp, WP_ITER);
+		RT_STAMP(wp, 2);      // closest-hit search
 		const bool hit = h.idx >= 0;
 
 		// ---- stage transitions ----------------------------------------------------------------
 		bool shade = false;       // start processLighting on (hp, hidx)
 		bool finish = false;      // write the pixel
+		bool mirror = false;      // reflect off the triangle just hit and trace on
+		float4 N4 = make_float4(0.f, 0.f, 0.f, 0.f);
+		if (hit && stage != ST_SHADOW) N4 = tri_plane<ACCEL>(sc, s_tri, lds_stride, PL_N, h.idx);
 		if (stage == ST_PRIMARY) {
 			if (!hit) {
 				color = make3(0.f, 0.f, 0.f);                                // Source.cpp:623-625
@@ -400,31 +503,20 @@ __global__ void __launch_bounds__(256) render_kernel(DevScene sc, FrameParams fp
 				finish = true;
 			} else {
 				if (COUNT) ctr[CTR_PXHIT]++;
-				const float4 N4 = tri_plane<ACCEL>(sc, s_tri, lds_stride, PL_N, h.idx);
 				if (N4.w > 0.5f) {                                           // Source.cpp:570
-					const vec3 normal = face_normal(d, xyz(N4));             // Source.cpp:561
-					d = normalize(reflect(d, normal));                       // Source.cpp:572
-					o = h.p;
-					skip = h.idx;                                            // Source.cpp:573
 					bounces = 0;
 					stage = ST_BOUNCE;
-					if (COUNT) { ctr[CTR_PXMIRROR]++; ctr[CTR_BOUNCE]++; }
+					mirror = true;                                           // Source.cpp:561, 572-573
+					if (COUNT) ctr[CTR_PXMIRROR]++;
 				} else {
 					hp = h.p; hidx = h.idx; dim = 1.0f;                      // Source.cpp:597
 					shade = true;
 				}
 			}
 		} else if (stage == ST_BOUNCE) {
-			float shin = 0.f;
-			float4 N4 = make_float4(0.f, 0.f, 0.f, 0.f);
-			if (hit) { N4 = tri_plane<ACCEL>(sc, s_tri, lds_stride, PL_N, h.idx); shin = N4.w; }
-			if (hit && bounces < fp.max_bounces && shin > 0.5f) {            // Source.cpp:575
-				const vec3 normal = face_normal(d, xyz(N4));                 // Source.cpp:576
-				d = normalize(reflect(d, normal));                           // Source.cpp:577
-				o = h.p;
-				skip = h.idx;                                                // Source.cpp:578
+			if (hit && bounces < fp.max_bounces && N4.w > 0.5f) {            // Source.cpp:575
 				bounces++;
-				if (COUNT) ctr[CTR_BOUNCE]++;
+				mirror = true;                                               // Source.cpp:576-578
 			} else if (hit) {                                                // Source.cpp:582
 				hp = h.p; hidx = h.idx;
 				dim = (float)(bounces * 1);                                  // Source.cpp:585
@@ -436,9 +528,8 @@ __global__ void __launch_bounds__(256) render_kernel(DevScene sc, FrameParams fp
 			}
 		} else if (stage == ST_SHADOW) {
 			if (!hit || h.t > dist) {                                        // Source.cpp:476
-				const float4 L = sc.lights[li];
-				const float f = 1.0f / (dist * dist) * L.w;                  // Source.cpp:488
-				const float modify = (float)((double)f / 255.0 / (double)255.0f);
+				const float f = 1.0f / (dist * dist) * intensity;            // Source.cpp:488
+				const float modify = (float)div255(div255((double)f));       // ... / 255.0 / 255.0f, in double
 				const float cr = tri_plane<ACCEL>(sc, s_tri, lds_stride, PL_P1, hidx).w;
 				const float cg = tri_plane<ACCEL>(sc, s_tri, lds_stride, PL_P2, hidx).w;
 				const float cb = tri_plane<ACCEL>(sc, s_tri, lds_stride, PL_P3, hidx).w;
@@ -451,6 +542,15 @@ __global__ void __launch_bounds__(256) render_kernel(DevScene sc, FrameParams fp
 			if (li >= sc.n_lights) finish = true;
 		}
 
+		if (mirror) {
+			// newNormal + reflect + normalize, then the next castRay starts on the mirror (one copy of
+			// this code serves Source.cpp:561/572-573 and Source.cpp:576-578)
+			const vec3 normal = face_normal(d, xyz(N4));
+			d = normalize(reflect(d, normal));
+			o = h.p;
+			skip = h.idx;
+			if (COUNT) ctr[CTR_BOUNCE]++;
+		}
 		if (shade) {
 			color = make3(0.f, 0.f, 0.f);                                    // Source.cpp:462
 			li = 0;
@@ -467,6 +567,7 @@ __global__ void __launch_bounds__(256) render_kernel(DevScene sc, FrameParams fp
 			const float inv = 1.0f / s;                                      // glm::normalize: v * inversesqrt(dot(v,v))
 			d = ray * inv;
 			dist = s;                                                        // magnitude(ray), Source.cpp:26-28
+			intensity = L.w;
 			o = hp;
 			skip = hidx;
 			if (COUNT) ctr[CTR_SHADOW]++;
@@ -483,8 +584,15 @@ __global__ void __launch_bounds__(256) render_kernel(DevScene sc, FrameParams fp
 			stage = ST_IDLE;
 			lit_any = false;
 		}
+		RT_STAMP(wp, 3);      // stage transitions, shading, store
 	}
 
+#ifdef RT_PROFILE
+	if (!COUNT && fp.counters != nullptr && (threadIdx.x & 63) == 0) {
+		for (int k = 0; k < 10; k++) atomicAdd(&fp.counters[k], (unsigned long long)wp.v[k]);
+		for (int k = 0; k < 10; k++) atomicAdd(&fp.counters[10 + k], wp.t[k]);
+	}
+#endif
 	if (COUNT) {
 		ctr[CTR_PLANE] = lc.plane; ctr[CTR_POINT] = lc.point; ctr[CTR_EDGE] = lc.edge; ctr[CTR_BOX] = lc.box;
 		flush_counters<COUNT>(fp.counters, ctr);
@@ -514,7 +622,8 @@ __global__ void __launch_bounds__(256) cast_rays_kernel(DevScene sc, int n, cons
 		skip = (sk >= 0.0f && sk < (float)sc.n_tris) ? (int)sk : -1;
 	}
 	LaneCounters lc = { 0, 0, 0, 0 };
-	const Hit h = trace<ACCEL, false>(sc, s_tri, lds_stride, nullptr, o, d, skip, live, false, 0.f, false, lc);
+	WaveProf wp = {};
+	const Hit h = trace<ACCEL, false>(sc, s_tri, lds_stride, nullptr, o, d, skip, live, false, 0.f, false, lc, wp);
 	if (live) {
 		float* w = out6 + (size_t)r * 6;
 		w[0] = h.idx >= 0 ? 1.0f : 0.0f;
@@ -533,7 +642,7 @@ DevScene dev_scene(const rt_scene* s, const DeviceState& d) {
 	sc.n_tris = (int)(s->tris.size() / RT_TRI_FLOATS);
 	sc.stride = d.stride;
 	sc.n_lights = (int)(s->lights.size() / 4);
-	sc.pad = 0;
+	sc.n_clusters = d.n_clusters;
 	sc.bvh_nodes = (const float4*)d.bvh_nodes;
 	sc.bvh_prim = (const int*)d.bvh_prim;
 	sc.bvh_root = d.bvh_root;
@@ -558,6 +667,7 @@ int launch_render(const DevScene& sc, const FrameParams& fp, int accel, int rend
 	(void)render_flags;
 	if (fp.width <= 0 || fp.local_rows <= 0) return RT_OK;
 	const long long tiles = (long long)((fp.width + 7) / 8) * ((fp.local_rows + 7) / 8);
+	if (tiles * 64 > 0xf0000000LL) { set_error("rt_render: %dx%d needs more than 2^32 work items", fp.width, fp.local_rows); return RT_ERR_LIMIT; }
 	int tpw = fp.tiles_per_wave > 0 ? fp.tiles_per_wave : pick_tiles_per_wave(tiles);
 	const long long waves = (tiles + tpw - 1) / tpw;
 	static const int env_block = [] { const char* e = getenv("RT355_BLOCK_THREADS"); int v = e ? atoi(e) : 0; return (v == 64 || v == 128 || v == 256) ? v : 0; }();

@@ -154,7 +154,7 @@ float scene_box(const std::vector<float>& tris, float lo[3], float hi[3]) {
 	return pad;
 }
 
-void flatten_planes(const std::vector<float>& tris, int stride, float pad, std::vector<float>& out) {
+int flatten_planes(const std::vector<float>& tris, int stride, float pad, std::vector<float>& out) {
 	const int n = (int)(tris.size() / RT_TRI_FLOATS);
 	const float inf = __builtin_huge_valf();
 	out.assign((size_t)PL_COUNT * stride * 4, 0.0f);
@@ -173,7 +173,7 @@ void flatten_planes(const std::vector<float>& tris, int stride, float pad, std::
 		q = plane(PL_E2, i); q[0] = e2[0]; q[1] = e2[1]; q[2] = e2[2];
 	}
 	// padded boxes of groups of RT_GROUP consecutive triangles
-	for (int g = 0; g * RT_GROUP < stride; g++) {
+	for (int g = 0; g < stride; g++) {      // every slot past the last group is an empty box
 		float l[3] = { inf, inf, inf }, h[3] = { -inf, -inf, -inf };
 		bool finite = pad - pad == 0.0f;
 		for (int i = g * RT_GROUP; i < (g + 1) * RT_GROUP && i < n; i++) {
@@ -192,6 +192,37 @@ void flatten_planes(const std::vector<float>& tris, int stride, float pad, std::
 			qh[k] = empty ? -inf : (finite ? h[k] + pad : inf);
 		}
 	}
+	// clusters: runs of consecutive groups whose common box stays small against the scene (half its
+	// scale at most, RT_CLUSTER_MAX_GROUPS groups at most).  A small object's groups share one box
+	// test; a wall-sized group stays alone (its cluster test would never cull anything).
+	const int n_groups = (n + RT_GROUP - 1) / RT_GROUP;
+	const float limit = pad * 500.0f;          // pad = 1e-3 * scene scale
+	int n_clusters = 0;
+	for (int g = 0; g < n_groups;) {
+		float l[3], h[3];
+		for (int k = 0; k < 3; k++) { l[k] = plane(PL_GLO, g)[k]; h[k] = plane(PL_GHI, g)[k]; }
+		int cnt = 1;
+		while (g + cnt < n_groups && cnt < RT_CLUSTER_MAX_GROUPS) {
+			float l2[3], h2[3];
+			bool small = true;
+			for (int k = 0; k < 3; k++) {
+				l2[k] = fminf(l[k], plane(PL_GLO, g + cnt)[k]);
+				h2[k] = fmaxf(h[k], plane(PL_GHI, g + cnt)[k]);
+				if (!(h2[k] - l2[k] <= limit)) small = false;
+			}
+			if (!small) break;
+			for (int k = 0; k < 3; k++) { l[k] = l2[k]; h[k] = h2[k]; }
+			cnt++;
+		}
+		float* ql = plane(PL_CLO, n_clusters);
+		float* qh = plane(PL_CHI, n_clusters);
+		for (int k = 0; k < 3; k++) { ql[k] = l[k]; qh[k] = h[k]; }
+		memcpy(ql + 3, &g, sizeof(int));
+		memcpy(qh + 3, &cnt, sizeof(int));
+		n_clusters++;
+		g += cnt;
+	}
+	return n_clusters;
 }
 
 } // namespace rt
