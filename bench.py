@@ -52,6 +52,8 @@ def parse():
                     choices=["room800", "stock800", "mirrors4k", "spheres800", "spheres4k", "sweep8k"])
     ap.add_argument("--mode", default="strict", choices=["strict", "fast"])
     ap.add_argument("--tiles-per-wave", type=int, default=0)
+    ap.add_argument("--frames-per-launch", type=int, default=16,
+                    help="frames of the camera path rendered by one launch (rt_render_frames_device); 1 = one launch per frame")
     ap.add_argument("--size", type=int, nargs=2, default=None, help="override the workload's frame size (experiments)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -181,7 +183,8 @@ def main():
         full = torch.empty(H * W * 3, dtype=torch.float32, device="cuda") if rank == 0 else None
         recv_bufs = [None] * world
     else:
-        fb = torch.empty(H * W * 3, dtype=torch.float32, device="cuda")
+        fpl = max(1, min(16, args.frames_per_launch))
+        fb = torch.empty(fpl * H * W * 3, dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
     # pre-marshalled arguments: the timed loop is then one ctypes call per frame
@@ -193,18 +196,41 @@ def main():
     trans_p = [a.ctypes.data_as(fptr) for a in trans]
     fb_ptr, stream_p, handle = C.c_void_p(fb.data_ptr()), C.c_void_p(stream), scene._h
 
+    batch_cache = {}
+
+    def launch_frames(frames):
+        """One call = one launch for up to 16 frames of the path (frames stay resident in `fb`).
+        The marshalled pose arrays of a batch are built once (warm-up) and reused."""
+        key = tuple(frames)
+        if key not in batch_cache:
+            cams = np.ascontiguousarray(np.stack([cam_c[f] for f in frames]), dtype=np.float32)
+            trs = np.ascontiguousarray(np.stack([trans[f] for f in frames]), dtype=np.float32)
+            batch_cache[key] = (cams, trs, cams.ctypes.data_as(fptr), trs.ctypes.data_as(fptr), C.c_size_t(H * W * 3))
+        _, _, cp, tp, stride = batch_cache[key]
+        rc = L.rt_render_frames_device(handle, dev, len(frames), cp, tp, W, H, D, mode, fb_ptr, stride, stream_p)
+        if rc != 0:
+            raise api.RtError(rc, L.rt_last_error().decode())
+
+    def run_steps(frames):
+        """`len(frames)` steps (one step = one frame)."""
+        if tile_mode:
+            for f in frames:
+                step(f)
+        else:
+            for i in range(0, len(frames), fpl):
+                launch_frames(frames[i:i + fpl])
+
     def step(f):
-        if not tile_mode:
-            rc = L.rt_render_device(handle, dev, cam_p[f], trans_p[f], W, H, D, mode, fb_ptr, stream_p)
-            if rc != 0:
-                raise api.RtError(rc, L.rt_last_error().decode())
-            return
         # row tiles: render this rank's interleaved tiles, then the one exchange step (RCCL)
         scene.render_tiles_device(dev, poses[f][0], trans[f], W, H, D, mode, tile_rows, rank, world, fb.data_ptr(), stream)
         sharding.gather_frame(dist, fb, full, rank, world, H, W, tile_rows, recv_bufs)
 
-    for s in range(args.warmup):
-        step(my_frames[s % len(my_frames)])
+    run_steps([my_frames[s % len(my_frames)] for s in range(args.warmup)])
+    if not tile_mode:                       # marshal every batch of the timed loop ahead of it
+        for i in range(0, len(my_frames), fpl):
+            key = tuple(my_frames[i:i + fpl])
+            if key not in batch_cache:
+                launch_frames(list(key))
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -212,15 +238,15 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for s in range(args.steps):
-        step(my_frames[s])
+    run_steps(my_frames)
     ev1.record()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps          # HIP events on the launch stream
+    n_launches = args.steps if tile_mode else (args.steps + fpl - 1) // fpl
+    kernel_ms = ev0.elapsed_time(ev1) / n_launches          # HIP events on the launch stream: mean launch duration
 
     my_rays = float(sum(rays_of[f] for f in my_frames))
     my_flops = float(sum(flops_of[f] for f in my_frames))
@@ -236,7 +262,8 @@ def main():
 
     if rank == 0:
         frames_total = args.steps if tile_mode else args.steps * world
-        achieved = (sum(flops_of[f] for f in my_frames) / args.steps) / (kernel_ms * 1e-3) / 1e12 if not tile_mode else None
+        flops_per_launch = sum(flops_of[f] for f in my_frames) / n_launches
+        achieved = flops_per_launch / (kernel_ms * 1e-3) / 1e12 if not tile_mode else None
         out = {
             "metric": "Mrays/s (primary+bounce+shadow) at 800x800" if args.workload.endswith("800") else "Mrays/s (primary+bounce+shadow)",
             "value": total_rays / wall / 1e6,
@@ -253,14 +280,15 @@ def main():
             "data": "synthetic",
             "config": {"workload": label, "accel": accel_name, "mode": args.mode, "width": W, "height": H, "max_bounces": D,
                        "triangles": scene.n_triangles, "lights": scene.n_lights,
-                       "frames": "64-pose camera sweep, frame (step*N + rank) % 64" if not tile_mode else "64-pose sweep, interleaved 16-row tiles, gather to rank 0",
+                       "frames_per_launch": (fpl if not tile_mode else 1),
+                       "frames": ("64-pose camera sweep, frame (step*N + rank) mod 64, %d frames per launch" % fpl) if not tile_mode else "64-pose sweep, interleaved 16-row tiles, gather to rank 0",
                        "rays_per_frame_mean": total_rays / frames_total, "parallelism": "frames x%d" % world if not tile_mode else "row tiles x%d" % world},
         }
         if achieved is not None:
             out["roofline"] = {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                                "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": read_traffic(args.workload),
                                "kernel_ms": kernel_ms,
-                               "flops_per_launch": sum(flops_of[f] for f in my_frames) / args.steps,
+                               "flops_per_launch": flops_per_launch, "frames_per_launch": fpl, "launches": n_launches,
                                "note": "FP32 VALU roofline (SURVEY 8d): nothing here is HBM- or MFMA-shaped; "
                                        "algorithmic FLOPs = 14/plane + 6/point + 17/edge term + 22/box + 32|29|30 per ray"}
         if world == 1 and not args.no_cpu:

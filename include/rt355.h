@@ -130,6 +130,18 @@ int rt_render_device(rt_scene* s, int device, const float cam_pos[3], const floa
                      int width, int height, int max_bounces, int render_flags,
                      float* d_out_rgb, void* hip_stream);
 
+/* Several frames of one committed scene — consecutive iterations of the reference's frame loop
+ * (Src:1126) whose camera poses are known in advance, e.g. a recorded camera path — rendered by as
+ * few launches as possible (up to RT_MAX_FRAMES_PER_LAUNCH frames each), asynchronously on
+ * `hip_stream`.  cam_pos3 is n_frames x 3 and trans16 n_frames x 16 (host memory, read before the
+ * call returns); frame f lands at d_out_rgb + f * frame_stride_floats, each in the usual layout.
+ * A single 800x800 frame is ~10 wavefronts per SIMD, too few to fill an MI355X; batching frames
+ * removes the per-launch ramp and tail.  Pixels are identical to rt_render's. */
+#define RT_MAX_FRAMES_PER_LAUNCH 16
+int rt_render_frames_device(rt_scene* s, int device, int n_frames, const float* cam_pos3, const float* trans16,
+                            int width, int height, int max_bounces, int render_flags,
+                            float* d_out_rgb, size_t frame_stride_floats, void* hip_stream);
+
 /* Interleaved row tiles for multi-GPU sharding: renders tiles t = tile_first,
  * tile_first + tile_stride, ... of `tile_rows` rows each (tile t covers rows [t*tile_rows,
  * (t+1)*tile_rows)) into a COMPACT device buffer that holds only this shard's rows, in

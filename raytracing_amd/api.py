@@ -33,7 +33,7 @@ SYMBOLS = (
     "rt_scene_add_triangles", "rt_scene_add_quad_half", "rt_scene_add_light", "rt_scene_load_rto",
     "rt_scene_triangle_count", "rt_scene_light_count", "rt_scene_get_triangles", "rt_scene_commit",
     "rt_scene_build_ms", "rt_scene_get_bvh", "rt_scene_accel", "rt_camera_trans", "rt_render", "rt_render_device",
-    "rt_render_tiles_device", "rt_shard_rows", "rt_render_stats", "rt_render_multi", "rt_cast_rays",
+    "rt_render_frames_device", "rt_render_tiles_device", "rt_shard_rows", "rt_render_stats", "rt_render_multi", "rt_cast_rays",
     "rt_device_count", "rt_set_tiles_per_wave", "rt_last_error", "rt_version",
 )
 
@@ -120,6 +120,7 @@ def lib():
     L.rt_render.argtypes = [vp, _fp, _fp, ci, ci, ci, ci, _fp]
     L.rt_render_device.argtypes = [vp, ci, _fp, _fp, ci, ci, ci, ci, vp, vp]
     L.rt_render_tiles_device.argtypes = [vp, ci, _fp, _fp, ci, ci, ci, ci, ci, ci, ci, vp, vp]
+    L.rt_render_frames_device.argtypes = [vp, ci, ci, _fp, _fp, ci, ci, ci, ci, vp, C.c_size_t, vp]
     L.rt_shard_rows.argtypes = [ci, ci, ci, ci]
     L.rt_render_stats.argtypes = [vp, _fp, _fp, ci, ci, ci, _fp, C.POINTER(Stats)]
     L.rt_render_multi.argtypes = [vp, C.POINTER(ci), ci, _fp, _fp, ci, ci, ci, ci, ci, _fp]
@@ -326,6 +327,16 @@ class Scene:
         cam, tr = _f32(cam_pos), _f32(trans16)
         _check(lib().rt_render_device(self._h, device, _p(cam), _p(tr), width, height, max_bounces, mode,
                                       C.c_void_p(d_out_ptr), C.c_void_p(stream)))
+
+    def render_frames_device(self, device: int, cam_pos3, trans16, width: int, height: int, max_bounces: int,
+                             mode: int, d_out_ptr: int, frame_stride_floats: int = 0, stream: int = 0) -> None:
+        """n frames (cam_pos3 (n,3), trans16 (n,16)) in as few launches as possible, asynchronously."""
+        cam, tr = _f32(cam_pos3).reshape(-1, 3), _f32(trans16).reshape(-1, 16)
+        if cam.shape[0] != tr.shape[0]:
+            raise ValueError("cam_pos3 and trans16 disagree on the frame count")
+        stride = frame_stride_floats or width * height * 3
+        _check(lib().rt_render_frames_device(self._h, device, cam.shape[0], _p(cam), _p(tr), width, height,
+                                             max_bounces, mode, C.c_void_p(d_out_ptr), stride, C.c_void_p(stream)))
 
     def render_tiles_device(self, device: int, cam_pos, trans16, width: int, height: int, max_bounces: int,
                             mode: int, tile_rows: int, tile_first: int, tile_stride: int,

@@ -92,8 +92,13 @@ DeviceState* committed(const char* fn, rt_scene* s, int device) {
 }
 
 void fill_frame(FrameParams& fp, const float cam[3], const float trans16[16], int w, int h, int depth) {
-	memcpy(fp.cam, cam, sizeof fp.cam);
-	memcpy(fp.m, trans16, sizeof fp.m);
+	memset(fp.cam, 0, sizeof fp.cam);
+	memset(fp.m, 0, sizeof fp.m);
+	memcpy(fp.cam[0], cam, 3 * sizeof(float));
+	memcpy(fp.m[0], trans16, 16 * sizeof(float));
+	fp.n_frames = 1;
+	fp.blocks_per_frame = 0;
+	fp.frame_stride = 0;
 	fp.width = w;
 	fp.height = h;
 	fp.max_bounces = depth;
@@ -237,6 +242,39 @@ int rt_render_tiles_device(rt_scene* s, int device, const float cam_pos[3], cons
 	fp.tiles_per_wave = g_tiles_per_wave_override;
 	fp.out = d_out_compact;
 	return launch_render(dev_scene(s, *d), fp, d->accel, render_flags, false, (hipStream_t)hip_stream);
+}
+
+int rt_render_frames_device(rt_scene* s, int device, int n_frames, const float* cam_pos3, const float* trans16,
+                            int width, int height, int max_bounces, int render_flags,
+                            float* d_out_rgb, size_t frame_stride_floats, void* hip_stream) {
+	if (n_frames < 0 || (n_frames > 0 && (!cam_pos3 || !trans16))) { set_error("rt_render_frames_device: bad frame list"); return RT_ERR_INVALID; }
+	if (n_frames == 0) return RT_OK;
+	int rc = check_frame_args("rt_render_frames_device", s, cam_pos3, trans16, width, height, max_bounces);
+	if (rc != RT_OK) return rc;
+	if (!d_out_rgb) { set_error("rt_render_frames_device: NULL output"); return RT_ERR_INVALID; }
+	if (frame_stride_floats < (size_t)width * height * 3) { set_error("rt_render_frames_device: frame stride smaller than a frame"); return RT_ERR_INVALID; }
+	if (render_flags != RT_RENDER_STRICT && render_flags != RT_RENDER_FAST) { set_error("rt_render_frames_device: unknown render flag %d", render_flags); return RT_ERR_INVALID; }
+	DeviceGuard g(device);
+	if (!g.ok) return g.rc;
+	DeviceState* d = committed("rt_render_frames_device", s, device);
+	if (!d) return RT_ERR_STATE;
+	const DevScene sc = dev_scene(s, *d);
+	for (int f0 = 0; f0 < n_frames; f0 += RT_MAX_FRAMES) {
+		const int nf = n_frames - f0 < RT_MAX_FRAMES ? n_frames - f0 : RT_MAX_FRAMES;
+		FrameParams fp;
+		fill_frame(fp, cam_pos3 + 3 * (size_t)f0, trans16 + 16 * (size_t)f0, width, height, max_bounces);
+		for (int k = 0; k < nf; k++) {
+			memcpy(fp.cam[k], cam_pos3 + 3 * (size_t)(f0 + k), 3 * sizeof(float));
+			memcpy(fp.m[k], trans16 + 16 * (size_t)(f0 + k), 16 * sizeof(float));
+		}
+		fp.n_frames = nf;
+		fp.frame_stride = (long long)frame_stride_floats;
+		fp.tiles_per_wave = g_tiles_per_wave_override;
+		fp.out = d_out_rgb + (size_t)f0 * frame_stride_floats;
+		rc = launch_render(sc, fp, d->accel, render_flags, false, (hipStream_t)hip_stream);
+		if (rc != RT_OK) return rc;
+	}
+	return RT_OK;
 }
 
 int rt_shard_rows(int height, int tile_rows, int tile_first, int tile_stride) {

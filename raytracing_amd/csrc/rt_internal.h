@@ -59,9 +59,16 @@ struct DevScene {
 // Per-launch frame description.  Rows are addressed as LOCAL rows of this shard:
 // local row ly -> tile ly / tile_rows -> global tile tile_first + that * tile_stride ->
 // global row y = tile * tile_rows + ly % tile_rows.  A whole frame is tile_first 0, stride 1.
+// One launch may render several frames of the same scene (a camera path: consecutive iterations
+// of the frame loop, Source.cpp:1126, with known poses): workgroups [f * blocks_per_frame,
+// (f+1) * blocks_per_frame) render frame f into out + f * frame_stride.
+#define RT_MAX_FRAMES 16
 struct FrameParams {
-	float cam[3];           // camera.position            Source.cpp:545
-	float m[16];            // trans, column-major        Source.cpp:1145-1147
+	float cam[RT_MAX_FRAMES][3];    // camera.position            Source.cpp:545
+	float m[RT_MAX_FRAMES][16];     // trans, column-major        Source.cpp:1145-1147
+	int n_frames;
+	unsigned int blocks_per_frame;  // set by the launcher
+	long long frame_stride;         // floats between consecutive frames in `out`
 	int width, height;      // Source.cpp:887-888
 	int max_bounces;        // Source.cpp:567
 	int tile_rows, tile_first, tile_stride;

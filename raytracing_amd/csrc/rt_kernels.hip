@@ -290,7 +290,7 @@ __device__ __forceinline__ int global_row(int ly, const FrameParams& fp) {
 }
 
 // Source.cpp:534-545: u, v in double then rounded; dir = (trans * vec4(u, v, 0.5, 1)).xyz
-__device__ __forceinline__ vec3 primary_dir(int x, int y, const FrameParams& fp) {
+__device__ __forceinline__ vec3 primary_dir(int x, int y, const FrameParams& fp, int frame) {
 	// (x - w/2.0) / (float)w in double, rounded to float.  For w, h < 2^22 the numerator is a
 	// half-integer below 2^22 and the denominator an integer: both exact in binary32, and rounding a
 	// binary64 quotient of binary32 operands to binary32 equals the correctly rounded binary32
@@ -303,7 +303,7 @@ __device__ __forceinline__ vec3 primary_dir(int x, int y, const FrameParams& fp)
 		v = (float)(((double)y - (double)fp.height / 2.0) / (double)(float)fp.height);
 		u = (float)(((double)x - (double)fp.width / 2.0) / (double)(float)fp.width);
 	}
-	const float* m = fp.m;
+	const float* m = fp.m[frame];
 	vec3 r;
 	r.x = (m[0] * u + m[4] * v) + (m[8] * 0.5f + m[12] * 1.0f);
 	r.y = (m[1] * u + m[5] * v) + (m[9] * 0.5f + m[13] * 1.0f);
@@ -395,7 +395,9 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES) render_kernel(DevScene sc, 
 	extern __shared__ float4 s_tri[];
 	const int lds_stride = lds_stride_of(sc.n_tris);
 	float* s_num0 = (float*)(s_tri + PL_COUNT * lds_stride);
-	const vec3 cam = make3(fp.cam[0], fp.cam[1], fp.cam[2]);
+	const int frame = fp.n_frames > 1 ? (int)(blockIdx.x / fp.blocks_per_frame) : 0;      // workgroup-uniform
+	const unsigned int block_in_frame = blockIdx.x - (unsigned int)frame * fp.blocks_per_frame;
+	const vec3 cam = make3(fp.cam[frame][0], fp.cam[frame][1], fp.cam[frame][2]);
 	if constexpr (ACCEL == 0) {
 		// stage all planes: consecutive lanes copy consecutive float4 (coalesced 1 KiB per wave op)
 		// (the device planes are zero-padded to a multiple of 64 triangles, so the batch padding reads zeros)
@@ -412,7 +414,7 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES) render_kernel(DevScene sc, 
 	const int tiles_y = (fp.local_rows + 7) >> 3;
 	// work items fit 32 bits: width * height * 3 < 2^31 is checked on the host (Source.cpp:550 uses int)
 	const unsigned int n_items = (unsigned int)tiles_x * (unsigned int)tiles_y * 64u;
-	const unsigned int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+	const unsigned int wave = __builtin_amdgcn_readfirstlane(block_in_frame * (blockDim.x >> 6) + (threadIdx.x >> 6));
 	unsigned int next = wave * (unsigned int)tiles_per_wave * 64u;  // wave-uniform cursor
 	unsigned int end = next + (unsigned int)tiles_per_wave * 64u;
 	if (end > n_items || end < next) end = n_items;
@@ -461,7 +463,7 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES) render_kernel(DevScene sc, 
 					if (px.inside) {
 						const int y = global_row(px.ly, fp);
 						out_index = (px.ly * fp.width + px.x) * 3;            // Source.cpp:550 (local rows)
-						d = primary_dir(px.x, y, fp);
+						d = primary_dir(px.x, y, fp, frame);
 						o = cam;                                             // Source.cpp:545
 						skip = -1;
 						stage = ST_PRIMARY;
@@ -579,7 +581,7 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES) render_kernel(DevScene sc, 
 			if (c.x > 1.0f) c.x = 1.0f;                                      // Source.cpp:602-610
 			if (c.y > 1.0f) c.y = 1.0f;
 			if (c.z > 1.0f) c.z = 1.0f;
-			float* out = fp.out + out_index;
+			float* out = fp.out + (long long)frame * fp.frame_stride + out_index;
 			out[0] = c.x; out[1] = c.y; out[2] = c.z;                        // Source.cpp:612-614
 			stage = ST_IDLE;
 			lit_any = false;
@@ -663,19 +665,23 @@ static int pick_tiles_per_wave(long long tiles) {
 	return (int)tpw;
 }
 
-int launch_render(const DevScene& sc, const FrameParams& fp, int accel, int render_flags, bool count, hipStream_t stream) {
+int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int render_flags, bool count, hipStream_t stream) {
 	(void)render_flags;
+	FrameParams fp = fp_in;
 	if (fp.width <= 0 || fp.local_rows <= 0) return RT_OK;
+	const int n_frames = fp.n_frames < 1 ? 1 : fp.n_frames;
 	const long long tiles = (long long)((fp.width + 7) / 8) * ((fp.local_rows + 7) / 8);
 	if (tiles * 64 > 0xf0000000LL) { set_error("rt_render: %dx%d needs more than 2^32 work items", fp.width, fp.local_rows); return RT_ERR_LIMIT; }
-	int tpw = fp.tiles_per_wave > 0 ? fp.tiles_per_wave : pick_tiles_per_wave(tiles);
+	int tpw = fp.tiles_per_wave > 0 ? fp.tiles_per_wave : pick_tiles_per_wave(tiles * n_frames);
 	const long long waves = (tiles + tpw - 1) / tpw;
 	static const int env_block = [] { const char* e = getenv("RT355_BLOCK_THREADS"); int v = e ? atoi(e) : 0; return (v == 64 || v == 128 || v == 256) ? v : 0; }();
 	const int threads = env_block ? env_block : 256;
 	const int wpb = threads / 64;
 	const long long blocks = (waves + wpb - 1) / wpb;
-	if (blocks > 0x7fffffffLL) { set_error("rt_render: frame too large (%lld workgroups)", blocks); return RT_ERR_LIMIT; }
-	const dim3 grid((unsigned)blocks), block((unsigned)threads);
+	if (blocks * n_frames > 0x7fffffffLL) { set_error("rt_render: frame too large (%lld workgroups)", blocks * n_frames); return RT_ERR_LIMIT; }
+	fp.n_frames = n_frames;
+	fp.blocks_per_frame = (unsigned int)blocks;
+	const dim3 grid((unsigned)(blocks * n_frames)), block((unsigned)threads);
 	if (accel == RT_ACCEL_LBVH) {
 		const size_t lds = (size_t)RT_STACK_LDS * threads * sizeof(int);
 		if (count) hipLaunchKernelGGL((render_kernel<2, true>), grid, block, lds, stream, sc, fp, tpw);
