@@ -656,12 +656,13 @@ DevScene dev_scene(const rt_scene* s, const DeviceState& d) {
 }
 
 static int pick_tiles_per_wave(long long tiles) {
-	// Enough waves to fill 256 CUs x 4 SIMDs several times over, long enough runs for the
-	// regeneration to have something to refill with.
-	const long long target_waves = 1024 * 32;
-	long long tpw = (tiles + target_waves - 1) / target_waves;
+	// One 8x8 tile per wave until a launch has more than ~128k waves (16 per wave slot of the
+	// chip); measured on the depth-16 mirror scene at 4K, longer tile runs only pay once the
+	// launch is that large — below it they cost balance at the tail.
+	const long long target_waves = 128 * 1024;
+	long long tpw = tiles / target_waves;
 	if (tpw < 1) tpw = 1;
-	if (tpw > 64) tpw = 64;
+	if (tpw > 16) tpw = 16;
 	return (int)tpw;
 }
 
