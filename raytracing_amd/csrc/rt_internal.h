@@ -29,6 +29,7 @@ namespace rt {
 // The `p` field of the reference record (Source.cpp:33, always == p1) is not uploaded.
 enum { PL_N = 0, PL_P1, PL_P2, PL_P3, PL_E0, PL_E1, PL_E2, PL_GLO, PL_GHI, PL_CLO, PL_CHI, PL_COUNT };
 #define RT_CLUSTER_MAX_GROUPS 16
+#define RT_BVH4_EMPTY 0x7ffffffe     /* unused child slot of a 4-wide node */
 #ifndef RT_GROUP
 #define RT_GROUP 2
 #endif
@@ -46,8 +47,9 @@ struct DevScene {
 	int n_lights;
 	int n_clusters;
 	// LBVH (null for brute force): see rt_lbvh.hip
-	const float4* bvh_nodes;
-	const int* bvh_prim;
+	const float4* bvh_nodes;   // binary Karras tree, 4 float4 per node (kept for inspection)
+	const float4* bvh4;        // 4-wide collapse of it, 8 float4 per node: what traversal walks
+	const float4* tri_aos;     // 8 float4 per triangle (N P1 P2 P3 E0 E1 E2 -): one burst per leaf test
 	int bvh_root;
 	int pad2;
 	// scene bounding box, padded (host: rt_api.cpp scene_box); +-inf when the scene has none
@@ -87,7 +89,8 @@ struct DeviceState {
 	void* planes = nullptr;
 	void* lights = nullptr;
 	void* bvh_nodes = nullptr;
-	void* bvh_prim = nullptr;
+	void* bvh4 = nullptr;
+	void* tri_aos = nullptr;
 	void* counters = nullptr;
 	int bvh_root = 0;
 	int stride = 0;

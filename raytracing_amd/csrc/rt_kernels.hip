@@ -388,7 +388,10 @@ template <int ACCEL, bool COUNT>
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 8      /* 64 VGPRs: 8 waves per SIMD; +6 % at steady state over 7 (measured) */
 #endif
-__global__ void __launch_bounds__(256, RT_MIN_WAVES) render_kernel(DevScene sc, FrameParams fp, int tiles_per_wave) {
+#ifndef RT_MIN_WAVES_LBVH
+#define RT_MIN_WAVES_LBVH 6
+#endif
+__global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : RT_MIN_WAVES) render_kernel(DevScene sc, FrameParams fp, int tiles_per_wave) {
 #ifdef RT_PROFILE
 	const unsigned long long t_start = __builtin_amdgcn_s_memtime();
 #endif
@@ -646,7 +649,8 @@ DevScene dev_scene(const rt_scene* s, const DeviceState& d) {
 	sc.n_lights = (int)(s->lights.size() / 4);
 	sc.n_clusters = d.n_clusters;
 	sc.bvh_nodes = (const float4*)d.bvh_nodes;
-	sc.bvh_prim = (const int*)d.bvh_prim;
+	sc.bvh4 = (const float4*)d.bvh4;
+	sc.tri_aos = (const float4*)d.tri_aos;
 	sc.bvh_root = d.bvh_root;
 	sc.pad2 = 0;
 	sc.far_guard = d.far_guard;

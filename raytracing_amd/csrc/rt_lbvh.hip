@@ -154,6 +154,65 @@ __global__ void __launch_bounds__(256) k_refit(const float4* __restrict__ planes
 	}
 }
 
+// 5. k_collapse4: the binary tree walked two levels at a time.  4-wide node i holds the
+//    grandchildren of binary node i (a child that is a leaf stands for itself), so a ray fetches
+//    half as many nodes in sequence — traversal is bound by that chain of dependent fetches, not
+//    by arithmetic.  Every binary node gets a 4-wide twin; only those at even depth are ever
+//    reached from the root, the rest are never read.  Layout (8 x float4 = 128 B):
+//      q0..q2 = lo.x/y/z of the 4 children, q3..q5 = hi.x/y/z, q6 = the 4 child references
+//      (RT_BVH4_EMPTY for an unused slot, whose box is inverted), q7 unused.
+__global__ void __launch_bounds__(256) k_collapse4(const float4* __restrict__ nodes, int n_nodes, float4* __restrict__ out) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_nodes) return;
+	const float inf = __builtin_huge_valf();
+	float lo[4][3], hi[4][3];
+	int ref[4];
+	int cnt = 0;
+	const float* nd = (const float*)(nodes + (size_t)i * 4);
+	for (int side = 0; side < 2; side++) {
+		const int c = __float_as_int(nd[12 + side]);
+		if (c >= 0) {
+			const float* cd = (const float*)(nodes + (size_t)c * 4);
+			for (int s2 = 0; s2 < 2; s2++) {
+				for (int k = 0; k < 3; k++) { lo[cnt][k] = cd[s2 * 6 + k]; hi[cnt][k] = cd[s2 * 6 + 3 + k]; }
+				ref[cnt++] = __float_as_int(cd[12 + s2]);
+			}
+		} else {
+			for (int k = 0; k < 3; k++) { lo[cnt][k] = nd[side * 6 + k]; hi[cnt][k] = nd[side * 6 + 3 + k]; }
+			ref[cnt++] = c;
+		}
+	}
+	for (; cnt < 4; cnt++) {
+		for (int k = 0; k < 3; k++) { lo[cnt][k] = inf; hi[cnt][k] = -inf; }
+		ref[cnt] = RT_BVH4_EMPTY;
+	}
+	float4* o = out + (size_t)i * 8;
+	o[0] = make_float4(lo[0][0], lo[1][0], lo[2][0], lo[3][0]);
+	o[1] = make_float4(lo[0][1], lo[1][1], lo[2][1], lo[3][1]);
+	o[2] = make_float4(lo[0][2], lo[1][2], lo[2][2], lo[3][2]);
+	o[3] = make_float4(hi[0][0], hi[1][0], hi[2][0], hi[3][0]);
+	o[4] = make_float4(hi[0][1], hi[1][1], hi[2][1], hi[3][1]);
+	o[5] = make_float4(hi[0][2], hi[1][2], hi[2][2], hi[3][2]);
+	o[6] = make_float4(__int_as_float(ref[0]), __int_as_float(ref[1]), __int_as_float(ref[2]), __int_as_float(ref[3]));
+	o[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// 6. k_aos: the SoA planes regrouped per triangle so that a leaf test is ONE burst of loads
+//    (N, P1 and, for candidates, the edge data) instead of up to four dependent round trips.
+__global__ void __launch_bounds__(256) k_aos(const float4* __restrict__ planes, int stride, int n, float4* __restrict__ out) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	float4* o = out + (size_t)i * 8;
+	o[0] = planes[PL_N * stride + i];
+	o[1] = planes[PL_P1 * stride + i];
+	o[2] = planes[PL_P2 * stride + i];
+	o[3] = planes[PL_P3 * stride + i];
+	o[4] = planes[PL_E0 * stride + i];
+	o[5] = planes[PL_E1 * stride + i];
+	o[6] = planes[PL_E2 * stride + i];
+	o[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 template <typename T>
 int dev_alloc(T** p, size_t count) {
 	hipError_t e = hipMalloc((void**)p, count * sizeof(T));
@@ -165,9 +224,11 @@ int dev_alloc(T** p, size_t count) {
 
 void lbvh_free(DeviceState& d) {
 	if (d.bvh_nodes) (void)hipFree(d.bvh_nodes);
-	if (d.bvh_prim) (void)hipFree(d.bvh_prim);
+	if (d.bvh4) (void)hipFree(d.bvh4);
+	if (d.tri_aos) (void)hipFree(d.tri_aos);
 	d.bvh_nodes = nullptr;
-	d.bvh_prim = nullptr;
+	d.bvh4 = nullptr;
+	d.tri_aos = nullptr;
 }
 
 int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
@@ -183,7 +244,7 @@ int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 	int *parent_int = nullptr, *parent_leaf = nullptr;
 	unsigned int* flags = nullptr;
 	void* temp = nullptr;
-	float4* nodes = nullptr;
+	float4 *nodes = nullptr, *nodes4 = nullptr, *aos = nullptr;
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	int rc = RT_OK;
 	auto cleanup = [&]() {
@@ -196,14 +257,16 @@ int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 		if (e0) (void)hipEventDestroy(e0);
 		if (e1) (void)hipEventDestroy(e1);
 	};
-#define LB_TRY(x) do { rc = (x); if (rc != RT_OK) { cleanup(); if (nodes) (void)hipFree(nodes); return rc; } } while (0)
-#define LB_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = hip_fail(e_, #x); cleanup(); if (nodes) (void)hipFree(nodes); return rc; } } while (0)
+#define LB_TRY(x) do { rc = (x); if (rc != RT_OK) { cleanup(); if (nodes) (void)hipFree(nodes); if (nodes4) (void)hipFree(nodes4); if (aos) (void)hipFree(aos); return rc; } } while (0)
+#define LB_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = hip_fail(e_, #x); cleanup(); if (nodes) (void)hipFree(nodes); if (nodes4) (void)hipFree(nodes4); if (aos) (void)hipFree(aos); return rc; } } while (0)
 	LB_TRY(dev_alloc(&keys, (size_t)n));
 	LB_TRY(dev_alloc(&keys_sorted, (size_t)n));
 	LB_TRY(dev_alloc(&parent_int, (size_t)n));
 	LB_TRY(dev_alloc(&parent_leaf, (size_t)n));
 	LB_TRY(dev_alloc(&flags, (size_t)n));
 	LB_TRY(dev_alloc(&nodes, (size_t)(n - 1) * 4));
+	LB_TRY(dev_alloc(&nodes4, (size_t)(n - 1) * 8));
+	LB_TRY(dev_alloc(&aos, (size_t)n * 8));
 	size_t temp_bytes = 0;
 	LB_HIP(rocprim::radix_sort_keys(nullptr, temp_bytes, keys, keys_sorted, (size_t)n, 0, 62, stream));
 	LB_HIP(hipMalloc(&temp, temp_bytes > 0 ? temp_bytes : 16));
@@ -227,6 +290,10 @@ int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 	hipLaunchKernelGGL(k_refit, dim3(blocks_n), dim3(256), 0, stream, planes, d.stride, n, keys_sorted, (float*)nodes,
 	                   parent_int, parent_leaf, flags, pad);
 	LB_HIP(hipGetLastError());
+	hipLaunchKernelGGL(k_collapse4, dim3(blocks_n), dim3(256), 0, stream, (const float4*)nodes, n - 1, nodes4);
+	LB_HIP(hipGetLastError());
+	hipLaunchKernelGGL(k_aos, dim3(blocks_n), dim3(256), 0, stream, planes, d.stride, n, aos);
+	LB_HIP(hipGetLastError());
 	LB_HIP(hipEventRecord(e1, stream));
 	LB_HIP(hipEventSynchronize(e1));
 	float ms = 0.f;
@@ -238,12 +305,16 @@ int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 		set_error("LBVH refit did not reach the root (flag %u)", root_flag);
 		cleanup();
 		(void)hipFree(nodes);
+		(void)hipFree(nodes4);
+		(void)hipFree(aos);
 		return RT_ERR_DEVICE;
 	}
 #undef LB_TRY
 #undef LB_HIP
 	cleanup();
 	d.bvh_nodes = nodes;
+	d.bvh4 = nodes4;
+	d.tri_aos = aos;
 	d.bvh_root = 0;
 	d.build_ms = ms;
 	return RT_OK;

@@ -9,6 +9,9 @@
 // (padded, see rt_lbvh.hip) only skip subtrees that cannot contain such a triangle; the triangle
 // test at a leaf is the reference's arithmetic, unfused, in its order.
 //
+// The tree is walked in its 4-wide form (rt_lbvh.hip k_collapse4): one 128-byte fetch, four slab
+// tests, children visited nearest first.  A leaf test reads the triangle's AoS record in one burst.
+//
 // Per-lane traversal stack: RT_STACK_LDS entries in LDS (entry k of lane l at [k * blockDim + l]:
 // conflict-free), the rest — a Karras tree over 62 key bits is at most 62 deep — in a private
 // array that is only touched by unusually deep paths.
@@ -23,19 +26,12 @@ struct Slab {
 	vec3 inv, oi;
 };
 
-__device__ __forceinline__ void slab2(const float4 q0, const float4 q1, const float4 q2, const Slab& s, float lim_hi,
-                                      float& tminL, float& tmaxL, float& tminR, float& tmaxR) {
-	// left box lo = (q0.x q0.y q0.z) hi = (q0.w q1.x q1.y); right box lo = (q1.z q1.w q2.x) hi = (q2.y q2.z q2.w)
-	const float lx0 = __builtin_fmaf(q0.x, s.inv.x, s.oi.x), lx1 = __builtin_fmaf(q0.w, s.inv.x, s.oi.x);
-	const float ly0 = __builtin_fmaf(q0.y, s.inv.y, s.oi.y), ly1 = __builtin_fmaf(q1.x, s.inv.y, s.oi.y);
-	const float lz0 = __builtin_fmaf(q0.z, s.inv.z, s.oi.z), lz1 = __builtin_fmaf(q1.y, s.inv.z, s.oi.z);
-	const float rx0 = __builtin_fmaf(q1.z, s.inv.x, s.oi.x), rx1 = __builtin_fmaf(q2.y, s.inv.x, s.oi.x);
-	const float ry0 = __builtin_fmaf(q1.w, s.inv.y, s.oi.y), ry1 = __builtin_fmaf(q2.z, s.inv.y, s.oi.y);
-	const float rz0 = __builtin_fmaf(q2.x, s.inv.z, s.oi.z), rz1 = __builtin_fmaf(q2.w, s.inv.z, s.oi.z);
-	tminL = fmaxf(fmaxf(fminf(lx0, lx1), fminf(ly0, ly1)), fmaxf(fminf(lz0, lz1), 0.0f));
-	tmaxL = fminf(fminf(fmaxf(lx0, lx1), fmaxf(ly0, ly1)), fminf(fmaxf(lz0, lz1), lim_hi));
-	tminR = fmaxf(fmaxf(fminf(rx0, rx1), fminf(ry0, ry1)), fmaxf(fminf(rz0, rz1), 0.0f));
-	tmaxR = fminf(fminf(fmaxf(rx0, rx1), fmaxf(ry0, ry1)), fminf(fmaxf(rz0, rz1), lim_hi));
+// compare-exchange of (key, ref) pairs, ascending by key
+__device__ __forceinline__ void cswap(float& ka, int& ra, float& kb, int& rb) {
+	const bool sw = kb < ka;
+	const float k0 = sw ? kb : ka, k1 = sw ? ka : kb;
+	const int r0 = sw ? rb : ra, r1 = sw ? ra : rb;
+	ka = k0; kb = k1; ra = r0; rb = r1;
 }
 
 template <bool COUNT>
@@ -46,58 +42,72 @@ __device__ __forceinline__ Hit cast_ray_lbvh(const DevScene& sc, int* lds_stack,
 	h.idx = -1;
 	h.p = make3(0.f, 0.f, 0.f);
 	const bool cull = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) < sc.far_guard;   // false for NaN too
-	float lim = cull ? fminf(exit_bound(sc, o, d), 1e9f) : 1e9f;
-	if (shadow) lim = fminf(lim, __uint_as_float(__float_as_uint(dist) + 1u));          // Source.cpp:476
-	lim = fminf(lim, 1e9f);
-	float lim_hi = lim + fabsf(lim) * RT_PREFILTER_REL;
 	Slab s;
 	{
 		const vec3 ds = make3(fabsf(d.x) < 1e-30f ? 1e-30f : d.x, fabsf(d.y) < 1e-30f ? 1e-30f : d.y, fabsf(d.z) < 1e-30f ? 1e-30f : d.z);
 		s.inv = make3(__builtin_amdgcn_rcpf(ds.x), __builtin_amdgcn_rcpf(ds.y), __builtin_amdgcn_rcpf(ds.z));
 		s.oi = make3(-(o.x * s.inv.x), -(o.y * s.inv.y), -(o.z * s.inv.z));
 	}
+	// where the ray leaves the padded scene box: no hit lies beyond (same arithmetic as the slabs)
+	const float ex = fminf(fminf(fmaxf(__builtin_fmaf(sc.bb_lo[0], s.inv.x, s.oi.x), __builtin_fmaf(sc.bb_hi[0], s.inv.x, s.oi.x)),
+	                             fmaxf(__builtin_fmaf(sc.bb_lo[1], s.inv.y, s.oi.y), __builtin_fmaf(sc.bb_hi[1], s.inv.y, s.oi.y))),
+	                       fmaxf(__builtin_fmaf(sc.bb_lo[2], s.inv.z, s.oi.z), __builtin_fmaf(sc.bb_hi[2], s.inv.z, s.oi.z)));
+	float lim = cull ? fminf(ex + fabsf(ex) * 1e-4f, 1e9f) : 1e9f;
+	if (shadow) lim = fminf(lim, __uint_as_float(__float_as_uint(dist) + 1u));          // Source.cpp:476
+	lim = fminf(lim, 1e9f);
+	float lim_hi = lim + fabsf(lim) * RT_PREFILTER_REL;
+	if (!cull) { s.inv = make3(0.f, 0.f, 0.f); s.oi = make3(0.f, 0.f, 0.f); }           // every (non-empty) box tests as hit
 	const int SENT = 0x7fffffff;
 	const int bd = blockDim.x, tid = threadIdx.x;
 	int ovf[RT_STACK_MAX - RT_STACK_LDS];
 	int sp = 0;
 	int node = live ? sc.bvh_root : SENT;
-	const float4* __restrict__ planes = sc.planes;
-	const int stride = sc.stride;
 
 	auto pop = [&]() -> int {
 		if (sp == 0) return SENT;
 		sp--;
 		return sp < RT_STACK_LDS ? lds_stack[sp * bd + tid] : ovf[sp - RT_STACK_LDS];
 	};
+	auto push = [&](int v) {
+		if (sp < RT_STACK_LDS) lds_stack[sp * bd + tid] = v;
+		else if (sp < RT_STACK_MAX) ovf[sp - RT_STACK_LDS] = v;
+		sp++;
+	};
 
+	const float inf = __builtin_huge_valf();
 	while (node != SENT) {
 		if (node >= 0) {
-			const float4* nd = sc.bvh_nodes + (size_t)node * 4;
-			const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
-			float tminL, tmaxL, tminR, tmaxR;
-			slab2(q0, q1, q2, s, lim_hi, tminL, tmaxL, tminR, tmaxR);
-			const bool hitL = !(tminL > tmaxL) || !cull;
-			const bool hitR = !(tminR > tmaxR) || !cull;
-			if (COUNT) lc.box += 2;
-			const int l = __float_as_int(q3.x), r = __float_as_int(q3.y);
-			if (hitL && hitR) {
-				const bool swap = tminR < tminL;
-				const int far = swap ? l : r;
-				node = swap ? r : l;
-				if (sp < RT_STACK_LDS) lds_stack[sp * bd + tid] = far;
-				else if (sp < RT_STACK_MAX) ovf[sp - RT_STACK_LDS] = far;
-				sp++;
-			} else if (hitL) {
-				node = l;
-			} else if (hitR) {
-				node = r;
-			} else {
-				node = pop();
+			const float4* nd = sc.bvh4 + (size_t)node * 8;
+			const float4 lox = nd[0], loy = nd[1], loz = nd[2], hix = nd[3], hiy = nd[4], hiz = nd[5], rf = nd[6];
+			float key[4];
+			int ref[4] = { __float_as_int(rf.x), __float_as_int(rf.y), __float_as_int(rf.z), __float_as_int(rf.w) };
+			const float lx[4] = { lox.x, lox.y, lox.z, lox.w }, ly[4] = { loy.x, loy.y, loy.z, loy.w }, lz[4] = { loz.x, loz.y, loz.z, loz.w };
+			const float hx[4] = { hix.x, hix.y, hix.z, hix.w }, hy[4] = { hiy.x, hiy.y, hiy.z, hiy.w }, hz[4] = { hiz.x, hiz.y, hiz.z, hiz.w };
+#pragma unroll
+			for (int c = 0; c < 4; c++) {
+				const float x0 = __builtin_fmaf(lx[c], s.inv.x, s.oi.x), x1 = __builtin_fmaf(hx[c], s.inv.x, s.oi.x);
+				const float y0 = __builtin_fmaf(ly[c], s.inv.y, s.oi.y), y1 = __builtin_fmaf(hy[c], s.inv.y, s.oi.y);
+				const float z0 = __builtin_fmaf(lz[c], s.inv.z, s.oi.z), z1 = __builtin_fmaf(hz[c], s.inv.z, s.oi.z);
+				const float tmin = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
+				const float tmax = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), lim_hi));
+				const bool present = ref[c] != RT_BVH4_EMPTY;
+				key[c] = (present && !(tmin > tmax)) ? tmin : inf;            // tmin >= 0 is never NaN
+				if (COUNT) lc.box += present;
 			}
+			// nearest first: sort the four (tmin, ref) pairs, push the farther hits, descend into the nearest
+			cswap(key[0], ref[0], key[1], ref[1]);
+			cswap(key[2], ref[2], key[3], ref[3]);
+			cswap(key[0], ref[0], key[2], ref[2]);
+			cswap(key[1], ref[1], key[3], ref[3]);
+			cswap(key[1], ref[1], key[2], ref[2]);
+			if (key[3] < inf) push(ref[3]);
+			if (key[2] < inf) push(ref[2]);
+			if (key[1] < inf) push(ref[1]);
+			node = key[0] < inf ? ref[0] : pop();
 		} else {
 			const int i = ~node;
-			const float4 N4 = planes[PL_N * stride + i];
-			const float4 P14 = planes[PL_P1 * stride + i];
+			const float4* T = sc.tri_aos + (size_t)i * 8;
+			const float4 N4 = T[0], P14 = T[1], P24 = T[2], P34 = T[3], E0 = T[4], E1 = T[5], E2 = T[6];
 			const vec3 nn = xyz(N4), p1 = xyz(P14);
 			const float t = dot(p1 - o, nn) / dot(d, nn);                                 // Source.cpp:383
 			const bool visit = (i != skip);                                               // Source.cpp:302
@@ -107,15 +117,10 @@ __device__ __forceinline__ Hit cast_ray_lbvh(const DevScene& sc, int* lds_stack,
 			bool found = false;
 			if (cand) {
 				const vec3 I = make3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);        // Source.cpp:389
-				const float4 E0 = planes[PL_E0 * stride + i];
 				if (dot(nn, cross(xyz(E0), I - p1)) > 0.0f) {                             // Source.cpp:392
 					if (COUNT) lc.edge++;
-					const float4 P24 = planes[PL_P2 * stride + i];
-					const float4 E1 = planes[PL_E1 * stride + i];
 					if (dot(nn, cross(xyz(E1), I - xyz(P24))) > 0.0f) {                   // Source.cpp:393
 						if (COUNT) lc.edge++;
-						const float4 P34 = planes[PL_P3 * stride + i];
-						const float4 E2 = planes[PL_E2 * stride + i];
 						if (dot(nn, cross(xyz(E2), I - xyz(P34))) > 0.0f) {               // Source.cpp:394
 							h.t = t; h.idx = i; h.p = I;                                  // Source.cpp:396
 							lim = t;
