@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--frames-per-launch", type=int, default=16,
                     help="frames of the camera path rendered by one launch (rt_render_frames_device); 1 = one launch per frame")
     ap.add_argument("--size", type=int, nargs=2, default=None, help="override the workload's frame size (experiments)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; gloo lets several ranks share one GPU to rehearse the N>1 path")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -141,12 +143,16 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the render loop has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = local_rank
+    dev = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev)
     dist = None
+    on_gpu = args.backend == "nccl"          # where the tensors handed to torch.distributed live
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group("gloo")
 
     desc, accel_name, label = make_workload(args.workload)
     if args.size:
@@ -180,7 +186,7 @@ def main():
         tile_rows = 16
         rows = api.shard_rows(H, tile_rows, rank, world)
         fb = torch.empty(rows * W * 3, dtype=torch.float32, device="cuda")
-        full = torch.empty(H * W * 3, dtype=torch.float32, device="cuda") if rank == 0 else None
+        full = torch.empty(H * W * 3, dtype=torch.float32, device="cuda" if on_gpu else "cpu") if rank == 0 else None
         recv_bufs = [None] * world
     else:
         fpl = max(1, min(16, args.frames_per_launch))
@@ -223,7 +229,8 @@ def main():
     def step(f):
         # row tiles: render this rank's interleaved tiles, then the one exchange step (RCCL)
         scene.render_tiles_device(dev, poses[f][0], trans[f], W, H, D, mode, tile_rows, rank, world, fb.data_ptr(), stream)
-        sharding.gather_frame(dist, fb, full, rank, world, H, W, tile_rows, recv_bufs)
+        # (gloo rehearsal: the shard is staged through host memory; RCCL sends it GPU to GPU)
+        sharding.gather_frame(dist, fb if on_gpu else fb.cpu(), full, rank, world, H, W, tile_rows, recv_bufs)
 
     run_steps([my_frames[s % len(my_frames)] for s in range(args.warmup)])
     if not tile_mode:                       # marshal every batch of the timed loop ahead of it
@@ -251,11 +258,11 @@ def main():
     my_rays = float(sum(rays_of[f] for f in my_frames))
     my_flops = float(sum(flops_of[f] for f in my_frames))
     if dist:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
         if not tile_mode:
-            r = torch.tensor([my_rays, my_flops], dtype=torch.float64, device="cuda")
+            r = torch.tensor([my_rays, my_flops], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
             dist.all_reduce(r, op=dist.ReduceOp.SUM)
             my_rays, my_flops = float(r[0].item()), float(r[1].item())
     total_rays, total_flops = my_rays, my_flops
