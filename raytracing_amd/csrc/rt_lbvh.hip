@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(256) k_refit(const float4* __restrict__ planes
 //    by arithmetic.  Every binary node gets a 4-wide twin; only those at even depth are ever
 //    reached from the root, the rest are never read.  Layout (8 x float4 = 128 B):
 //      q0..q2 = lo.x/y/z of the 4 children, q3..q5 = hi.x/y/z, q6 = the 4 child references
-//      (RT_BVH4_EMPTY for an unused slot, whose box is inverted), q7 unused.
+//      (RT_BVH4_EMPTY for an unused slot, whose box is the point +inf: never hit), q7 unused.
 __global__ void __launch_bounds__(256) k_collapse4(const float4* __restrict__ nodes, int n_nodes, float4* __restrict__ out) {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n_nodes) return;
@@ -183,7 +183,9 @@ __global__ void __launch_bounds__(256) k_collapse4(const float4* __restrict__ no
 		}
 	}
 	for (; cnt < 4; cnt++) {
-		for (int k = 0; k < 3; k++) { lo[cnt][k] = inf; hi[cnt][k] = -inf; }
+		// lo = hi = +inf: both slab distances of every axis are +inf or both -inf, so tmin > tmax for
+		// every ray (an inverted box would NOT do: min/max of the two slab distances is symmetric)
+		for (int k = 0; k < 3; k++) { lo[cnt][k] = inf; hi[cnt][k] = inf; }
 		ref[cnt] = RT_BVH4_EMPTY;
 	}
 	float4* o = out + (size_t)i * 8;
