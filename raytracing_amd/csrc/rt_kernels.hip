@@ -688,7 +688,7 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 	fp.blocks_per_frame = (unsigned int)blocks;
 	const dim3 grid((unsigned)(blocks * n_frames)), block((unsigned)threads);
 	if (accel == RT_ACCEL_LBVH) {
-		const size_t lds = (size_t)RT_STACK_LDS * 256 * sizeof(int);      // [entry][lane] with a fixed 256-lane pitch
+		const size_t lds = (size_t)RT_STACK_LDS * threads * sizeof(int);   // [entry][lane], pitch = workgroup size
 		if (count) hipLaunchKernelGGL((render_kernel<2, true>), grid, block, lds, stream, sc, fp, tpw);
 		else hipLaunchKernelGGL((render_kernel<2, false>), grid, block, lds, stream, sc, fp, tpw);
 	} else if (sc.n_tris <= RT_LDS_MAX_TRIS) {

@@ -17,7 +17,9 @@
 // array that is only touched by unusually deep paths.
 #pragma once
 
-#define RT_STACK_LDS 32
+#ifndef RT_STACK_LDS
+#define RT_STACK_LDS 16      /* measured: 12-16 beats 24 and 32 (occupancy); deeper paths spill to a private array */
+#endif
 #define RT_STACK_MAX 64
 
 namespace rt {
