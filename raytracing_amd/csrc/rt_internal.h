@@ -48,7 +48,7 @@ struct DevScene {
 	int n_clusters;
 	// LBVH (null for brute force): see rt_lbvh.hip
 	const float4* bvh_nodes;   // binary Karras tree, 4 float4 per node (kept for inspection)
-	const float4* bvh4;        // 4-wide collapse of it, 8 float4 per node: what traversal walks
+	const uint4* bvh4;         // 4-wide quantised collapse of it, 64 B per node: what traversal walks
 	const float4* tri_aos;     // 8 float4 per triangle (N P1 P2 P3 E0 E1 E2 -): one burst per leaf test
 	int bvh_root;
 	int pad2;

@@ -344,7 +344,7 @@ __device__ __forceinline__ Hit trace(const DevScene& sc, const float4* lds_tri, 
                                      vec3 o, vec3 d, int skip, bool live, bool shadow, float dist, bool all_primary,
                                      LaneCounters& lc, WaveProf& wp) {
 	if constexpr (ACCEL == 2) {
-		return cast_ray_lbvh<COUNT>(sc, (int*)lds_tri, o, d, skip, live, shadow, dist, lc);
+		return cast_ray_lbvh<COUNT>(sc, (int*)lds_tri, o, d, skip, live, shadow, dist, lc, wp);
 	} else if constexpr (COUNT) {
 		// instrumented, reference-order loop: the counters follow Source.cpp's own short-circuits
 		if constexpr (ACCEL == 0) return cast_ray_brute<true>(lds_tri, lds_stride, sc.n_tris, o, d, skip, live, lc);
@@ -649,7 +649,7 @@ DevScene dev_scene(const rt_scene* s, const DeviceState& d) {
 	sc.n_lights = (int)(s->lights.size() / 4);
 	sc.n_clusters = d.n_clusters;
 	sc.bvh_nodes = (const float4*)d.bvh_nodes;
-	sc.bvh4 = (const float4*)d.bvh4;
+	sc.bvh4 = (const uint4*)d.bvh4;
 	sc.tri_aos = (const float4*)d.tri_aos;
 	sc.bvh_root = d.bvh_root;
 	sc.pad2 = 0;

@@ -38,7 +38,8 @@ __device__ __forceinline__ void cswap(float& ka, int& ra, float& kb, int& rb) {
 
 template <bool COUNT>
 __device__ __forceinline__ Hit cast_ray_lbvh(const DevScene& sc, int* lds_stack, vec3 o, vec3 d, int skip, bool live,
-                                             bool shadow, float dist, LaneCounters& lc) {
+                                             bool shadow, float dist, LaneCounters& lc, WaveProf& wp) {
+	RT_PROF(wp, WP_TRACE);
 	Hit h;
 	h.t = 1e9f;                                                          // Source.cpp:278
 	h.idx = -1;
@@ -78,24 +79,37 @@ __device__ __forceinline__ Hit cast_ray_lbvh(const DevScene& sc, int* lds_stack,
 
 	const float inf = __builtin_huge_valf();
 	while (node != SENT) {
+#ifdef RT_PROFILE
+		{   // wave-level: loop trips, trips with lanes at inner nodes / at leaves, and lane-visits of each kind
+			const unsigned long long mn = __builtin_amdgcn_ballot_w64(node >= 0), ml = __builtin_amdgcn_ballot_w64(node < 0);
+			wp.v[WP_ITER]++;
+			if (mn) { wp.v[WP_GROUP]++; wp.v[WP_INBOX] += __popcll(mn); }
+			if (ml) { wp.v[WP_TRI]++; wp.v[WP_MAYBE] += __popcll(ml); }
+		}
+#endif
 		if (node >= 0) {
-			const float4* nd = sc.bvh4 + (size_t)node * 8;
-			const float4 lox = nd[0], loy = nd[1], loz = nd[2], hix = nd[3], hiy = nd[4], hiz = nd[5], rf = nd[6];
+			const uint4* nd = sc.bvh4 + (size_t)node * 4;
+			const uint4 w0 = nd[0], w1 = nd[1], w2 = nd[2];
+			const uint2 w3 = *(const uint2*)(nd + 3);
+			// per axis: t(q) = (p + q * 2^e) * inv + oi = q * A + B
+			const float Ax = __uint_as_float((w0.w & 0xffu) << 23) * s.inv.x, Bx = __builtin_fmaf(__uint_as_float(w0.x), s.inv.x, s.oi.x);
+			const float Ay = __uint_as_float(((w0.w >> 8) & 0xffu) << 23) * s.inv.y, By = __builtin_fmaf(__uint_as_float(w0.y), s.inv.y, s.oi.y);
+			const float Az = __uint_as_float(((w0.w >> 16) & 0xffu) << 23) * s.inv.z, Bz = __builtin_fmaf(__uint_as_float(w0.z), s.inv.z, s.oi.z);
 			float key[4];
-			int ref[4] = { __float_as_int(rf.x), __float_as_int(rf.y), __float_as_int(rf.z), __float_as_int(rf.w) };
-			const float lx[4] = { lox.x, lox.y, lox.z, lox.w }, ly[4] = { loy.x, loy.y, loy.z, loy.w }, lz[4] = { loz.x, loz.y, loz.z, loz.w };
-			const float hx[4] = { hix.x, hix.y, hix.z, hix.w }, hy[4] = { hiy.x, hiy.y, hiy.z, hiy.w }, hz[4] = { hiz.x, hiz.y, hiz.z, hiz.w };
+			int ref[4] = { (int)w1.x, (int)w1.y, (int)w1.z, (int)w1.w };
+#define RT_QB(word, c) ((float)(((word) >> (8 * (c))) & 0xffu))      /* v_cvt_f32_ubyteN */
 #pragma unroll
 			for (int c = 0; c < 4; c++) {
-				const float x0 = __builtin_fmaf(lx[c], s.inv.x, s.oi.x), x1 = __builtin_fmaf(hx[c], s.inv.x, s.oi.x);
-				const float y0 = __builtin_fmaf(ly[c], s.inv.y, s.oi.y), y1 = __builtin_fmaf(hy[c], s.inv.y, s.oi.y);
-				const float z0 = __builtin_fmaf(lz[c], s.inv.z, s.oi.z), z1 = __builtin_fmaf(hz[c], s.inv.z, s.oi.z);
+				const float x0 = __builtin_fmaf(RT_QB(w2.x, c), Ax, Bx), x1 = __builtin_fmaf(RT_QB(w2.w, c), Ax, Bx);
+				const float y0 = __builtin_fmaf(RT_QB(w2.y, c), Ay, By), y1 = __builtin_fmaf(RT_QB(w3.x, c), Ay, By);
+				const float z0 = __builtin_fmaf(RT_QB(w2.z, c), Az, Bz), z1 = __builtin_fmaf(RT_QB(w3.y, c), Az, Bz);
 				const float tmin = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
 				const float tmax = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), lim_hi));
 				const bool present = ref[c] != RT_BVH4_EMPTY;
 				key[c] = (present && !(tmin > tmax)) ? tmin : inf;            // tmin >= 0 is never NaN
 				if (COUNT) lc.box += present;
 			}
+#undef RT_QB
 			// nearest first: sort the four (tmin, ref) pairs, push the farther hits, descend into the nearest
 			cswap(key[0], ref[0], key[1], ref[1]);
 			cswap(key[2], ref[2], key[3], ref[3]);
