@@ -173,3 +173,98 @@ def test_frame_batch_equals_single_frames():
                 assert np.array_equal(_bits(got[i, :n].reshape(desc.height, desc.width, 3)), _bits(singles[i])), (count, i)
                 assert np.all(got[i, n:] == -1.0)
     assert not np.array_equal(singles[0], singles[19])
+
+
+def _soup(seed, n, extent, w=96, h=64, depth=3, lights=3, cam=None, needles=False):
+    """Random triangle soup (nothing like the reference's room): arbitrary orientations, sizes
+    from slivers to scene-sized, mirrors, several lights — the inputs on which the work-skipping
+    filters (boxes, clusters, reciprocal prefilter, exit bound) have to stay invisible."""
+    rng = np.random.default_rng(seed)
+    sc = scenes.SceneDesc("soup%d" % seed, width=w, height=h, depth=depth)
+    for i in range(n):
+        c = rng.uniform(-extent, extent, 3)
+        size = extent * (10.0 ** rng.uniform(-2.0, 0.0))
+        a, b, d = (c + rng.normal(size=3) * size for _ in range(3))
+        if needles and i % 5 == 0:
+            d = a + (b - a) * 0.5 + rng.normal(size=3) * size * 1e-4      # sliver: aspect ~1:10000
+        sc.tri(a, b, d, rng.integers(0, 256, 3), 1.0 if rng.random() < 0.25 else 0.0)
+    for _ in range(lights):
+        sc.light(rng.uniform(-extent, extent, 3), float(10.0 ** rng.uniform(1, 4)))
+    if cam is None:
+        cam = (rng.uniform(-extent, extent, 3), rng.uniform(-180, 180, 3))
+    sc.cam_pos, sc.cam_rot = tuple(map(float, cam[0])), tuple(map(float, cam[1]))
+    return sc
+
+
+@pytest.mark.parametrize("seed,n,extent,kw", [
+    (1, 40, 10.0, {}),
+    (2, 150, 10.0, {"needles": True}),
+    (3, 300, 1.0, {"depth": 8, "lights": 8, "cam": ((0.0, 0.0, 2.5), (180.0, 0.0, 0.0))}),
+    (4, 25, 1e4, {}),                                            # large coordinates
+    (5, 60, 1e-3, {"cam": ((0.0, 0.0, 2.5e-3), (180.0, 0.0, 0.0))}),   # tiny scene
+    (6, 80, 10.0, {"cam": ((0.0, 0.0, 3e4), (180.0, 0.0, 0.0)), "w": 4096, "h": 4}),   # camera beyond far_guard: boxes switched off
+    (7, 200, 10.0, {"cam": ((0.0, 0.0, 30.0), (180.0, 0.0, 0.0)), "lights": 5}),   # outside, looking in
+    (8, 7, 5.0, {"w": 33, "h": 17, "cam": ((0.0, 0.0, 12.0), (180.0, 0.0, 0.0))}),
+])
+def test_random_soups_vs_oracle(oracle, seed, n, extent, kw):
+    desc = _soup(seed, n, extent, **kw)
+    want = oracle.render_desc(desc, threads=8)
+    got = _render(desc, api.ACCEL_BRUTE)
+    assert np.array_equal(_bits(got), _bits(want)), "brute force: %d px differ" % int((_bits(got) != _bits(want)).any(axis=2).sum())
+    got2 = _render(desc, api.ACCEL_LBVH)
+    assert np.array_equal(_bits(got2), _bits(want)), "LBVH: %d px differ" % int((_bits(got2) != _bits(want)).any(axis=2).sum())
+    assert np.isfinite(want).all() or True
+
+
+def test_tiny_frames_and_many_lights(oracle):
+    for w, h in [(1, 1), (2, 3), (9, 1), (1, 9)]:
+        desc = scenes.two_lights(w, h)
+        assert np.array_equal(_bits(_render(desc)), _bits(oracle.render_desc(desc)))
+    desc = scenes.stock(80, 60)
+    for k in range(6):
+        desc.light((3.0 * k - 7, 8 - k, 2.0 * k - 5), 200.0 + 300 * k)
+    assert np.array_equal(_bits(_render(desc)), _bits(oracle.render_desc(desc, threads=4)))
+
+
+def test_far_origin_rays_vs_oracle(oracle):
+    """castRay from origins 10^3..10^6 scene scales away, aimed into the scene: beyond far_guard the
+    box tests are switched off (brute force) or the tree is bypassed (LBVH); answers must not change."""
+    desc = _soup(11, 120, 10.0)
+    tris, _ = oracle.build_scene(desc)
+    rng = np.random.default_rng(3)
+    rays = []
+    for k in range(600):
+        target = rng.uniform(-10, 10, 3)
+        direction = rng.normal(size=3)
+        direction /= np.linalg.norm(direction)
+        dist = 10.0 ** rng.uniform(1, 7.5)
+        o = target - direction * dist
+        scale = 1.0 if k % 2 else dist          # unit and unnormalised directions
+        rays.append([*o, *(direction * scale), -1.0])
+    rays = np.array(rays, np.float32)
+    want = np.stack([oracle.cast_ray(tris, r[0:3], r[3:6], -1) for r in rays])
+    for accel in (api.ACCEL_BRUTE, api.ACCEL_LBVH):
+        with api.Scene.from_desc(desc) as sc:
+            sc.commit(0, accel)
+            got = sc.cast_rays(rays)
+        assert np.array_equal(got[:, 0], want[:, 0]), accel
+        assert np.array_equal(got[:, 1], want[:, 1]), accel
+        hit = want[:, 0] > 0
+        assert np.array_equal(_bits(got[hit]), _bits(want[hit])), accel
+    assert 20 < (want[:, 0] > 0).sum() < 600
+
+
+def test_many_random_soups_vs_oracle(oracle):
+    """30 more seeds at 48x32, alternating needles / scales / camera placement."""
+    bad = []
+    for seed in range(100, 130):
+        extent = [10.0, 1.0, 300.0][seed % 3]
+        cam = None if seed % 2 else ((0.0, 0.0, 2.5 * extent), (180.0, 0.0, 0.0))
+        desc = _soup(seed, 20 + 9 * (seed % 17), extent, w=48, h=32, depth=1 + seed % 5, lights=1 + seed % 3,
+                     cam=cam, needles=bool(seed % 4 == 0))
+        want = oracle.render_desc(desc, threads=4)
+        for accel in (api.ACCEL_BRUTE, api.ACCEL_LBVH):
+            got = _render(desc, accel)
+            if not np.array_equal(_bits(got), _bits(want)):
+                bad.append((seed, accel, int((_bits(got) != _bits(want)).any(axis=2).sum())))
+    assert not bad, bad
