@@ -97,16 +97,20 @@ __device__ __forceinline__ Hit cast_ray_lbvh(const DevScene& sc, int* lds_stack,
 			const float Az = __uint_as_float(((w0.w >> 16) & 0xffu) << 23) * s.inv.z, Bz = __builtin_fmaf(__uint_as_float(w0.z), s.inv.z, s.oi.z);
 			float key[4];
 			int ref[4] = { (int)w1.x, (int)w1.y, (int)w1.z, (int)w1.w };
+			// A's sign is the ray direction's: the near slab plane is `lo` when it is positive, `hi` otherwise.
+			// Picking the words once per node replaces the per-child min/max of the two slab distances.
+			const unsigned int nx = Ax >= 0.0f ? w2.x : w2.w, fx = Ax >= 0.0f ? w2.w : w2.x;
+			const unsigned int ny = Ay >= 0.0f ? w2.y : w3.x, fy = Ay >= 0.0f ? w3.x : w2.y;
+			const unsigned int nz = Az >= 0.0f ? w2.z : w3.y, fz = Az >= 0.0f ? w3.y : w2.z;
 #define RT_QB(word, c) ((float)(((word) >> (8 * (c))) & 0xffu))      /* v_cvt_f32_ubyteN */
 #pragma unroll
 			for (int c = 0; c < 4; c++) {
-				const float x0 = __builtin_fmaf(RT_QB(w2.x, c), Ax, Bx), x1 = __builtin_fmaf(RT_QB(w2.w, c), Ax, Bx);
-				const float y0 = __builtin_fmaf(RT_QB(w2.y, c), Ay, By), y1 = __builtin_fmaf(RT_QB(w3.x, c), Ay, By);
-				const float z0 = __builtin_fmaf(RT_QB(w2.z, c), Az, Bz), z1 = __builtin_fmaf(RT_QB(w3.y, c), Az, Bz);
-				const float tmin = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
-				const float tmax = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), lim_hi));
+				const float tmin = fmaxf(fmaxf(__builtin_fmaf(RT_QB(nx, c), Ax, Bx), __builtin_fmaf(RT_QB(ny, c), Ay, By)),
+				                         fmaxf(__builtin_fmaf(RT_QB(nz, c), Az, Bz), 0.0f));
+				const float tmax = fminf(fminf(__builtin_fmaf(RT_QB(fx, c), Ax, Bx), __builtin_fmaf(RT_QB(fy, c), Ay, By)),
+				                         fminf(__builtin_fmaf(RT_QB(fz, c), Az, Bz), lim_hi));
 				const bool present = ref[c] != RT_BVH4_EMPTY;
-				key[c] = (present && !(tmin > tmax)) ? tmin : inf;            // tmin >= 0 is never NaN
+				key[c] = (present && !(tmin > tmax)) ? tmin : inf;            // A, B are finite: no NaN here
 				if (COUNT) lc.box += present;
 			}
 #undef RT_QB
