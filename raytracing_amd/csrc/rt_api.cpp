@@ -351,6 +351,8 @@ int rt_render_stats(rt_scene* s, const float cam_pos[3], const float trans16[16]
 #ifdef RT_PROFILE
 	fprintf(stderr, "RT_PROFILE cycles: staging %llu setup %llu trace-rest %llu shade %llu | boxes %llu prefilter %llu exact %llu bounds %llu\n",
 	        c[10], c[11], c[12], c[13], c[14], c[15], c[16], c[17]);
+	fprintf(stderr, "RT_PROFILE lbvh: trips %llu | node trips %llu lanes %llu | leaf trips %llu lanes %llu | distinct nodes %llu, trips with 1 node %llu, with <=4 %llu\n",
+	        c[20], c[21], c[22], c[23], c[24], c[25], c[26], c[27]);
 #endif
 	return RT_OK;
 }

@@ -43,7 +43,7 @@ struct Hit {
 
 // Wave-level event counts for tuning (RT_PROFILE builds only; scripts/prof_build.sh).
 #ifdef RT_PROFILE
-struct WaveProf { unsigned int v[10]; unsigned long long t[10]; unsigned long long last; };
+struct WaveProf { unsigned int v[10]; unsigned long long t[10]; unsigned long long last; unsigned long long* g; };
 #define RT_PROF(p, k) ((p).v[k]++)
 // segment stamp: adds the cycles since the previous stamp to segment k (diagnostic builds only)
 #define RT_STAMP(p, k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
@@ -448,6 +448,7 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : RT_MIN_W
 	WaveProf wp = {};
 #ifdef RT_PROFILE
 	wp.last = __builtin_amdgcn_s_memtime();
+	wp.g = fp.counters;
 	__builtin_amdgcn_s_waitcnt(0xC07F);
 	wp.t[0] = wp.last - t_start;       // argument loads + LDS staging
 #endif
@@ -688,7 +689,7 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 	fp.blocks_per_frame = (unsigned int)blocks;
 	const dim3 grid((unsigned)(blocks * n_frames)), block((unsigned)threads);
 	if (accel == RT_ACCEL_LBVH) {
-		const size_t lds = (size_t)RT_STACK_LDS * threads * sizeof(int);   // [entry][lane], pitch = workgroup size
+		const size_t lds = (size_t)RT_STACK_LDS * RT_STACK_PITCH * sizeof(int);   // [entry][lane]
 		if (count) hipLaunchKernelGGL((render_kernel<2, true>), grid, block, lds, stream, sc, fp, tpw);
 		else hipLaunchKernelGGL((render_kernel<2, false>), grid, block, lds, stream, sc, fp, tpw);
 	} else if (sc.n_tris <= RT_LDS_MAX_TRIS) {

@@ -21,6 +21,7 @@
 #define RT_STACK_LDS 16      /* measured: 12-16 beats 24 and 32 (occupancy); deeper paths spill to a private array */
 #endif
 #define RT_STACK_MAX 64
+#define RT_STACK_PITCH 256   /* lanes per workgroup the LDS stack is laid out for */
 
 namespace rt {
 
@@ -61,18 +62,21 @@ __device__ __forceinline__ Hit cast_ray_lbvh(const DevScene& sc, int* lds_stack,
 	float lim_hi = lim + fabsf(lim) * RT_PREFILTER_REL;
 	if (!cull) { s.inv = make3(0.f, 0.f, 0.f); s.oi = make3(0.f, 0.f, 0.f); }           // every (non-empty) box tests as hit
 	const int SENT = 0x7fffffff;
-	const int bd = blockDim.x, tid = threadIdx.x;
+	const int tid = threadIdx.x;
 	int ovf[RT_STACK_MAX - RT_STACK_LDS];
 	int sp = 0;
 	int node = live ? sc.bvh_root : SENT;
+	int* const slot0 = lds_stack + tid;                                  // entry k of this lane: slot0[k * RT_STACK_PITCH]
 
-	auto pop = [&]() -> int {
+	// General stack access (any depth); the loop below uses it only when some lane of the wave is
+	// near or beyond the LDS part, which is wave-uniformly tested so the common path has no branches.
+	auto pop_any = [&]() -> int {
 		if (sp == 0) return SENT;
 		sp--;
-		return sp < RT_STACK_LDS ? lds_stack[sp * bd + tid] : ovf[sp - RT_STACK_LDS];
+		return sp < RT_STACK_LDS ? slot0[sp * RT_STACK_PITCH] : ovf[sp - RT_STACK_LDS];
 	};
-	auto push = [&](int v) {
-		if (sp < RT_STACK_LDS) lds_stack[sp * bd + tid] = v;
+	auto push_any = [&](int v) {
+		if (sp < RT_STACK_LDS) slot0[sp * RT_STACK_PITCH] = v;
 		else if (sp < RT_STACK_MAX) ovf[sp - RT_STACK_LDS] = v;
 		sp++;
 	};
@@ -80,11 +84,24 @@ __device__ __forceinline__ Hit cast_ray_lbvh(const DevScene& sc, int* lds_stack,
 	const float inf = __builtin_huge_valf();
 	while (node != SENT) {
 #ifdef RT_PROFILE
-		{   // wave-level: loop trips, trips with lanes at inner nodes / at leaves, and lane-visits of each kind
+		if (wp.g) {   // exact wave-level counts (slow: one atomic per event from the first active lane); counters 20..27
+			const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
 			const unsigned long long mn = __builtin_amdgcn_ballot_w64(node >= 0), ml = __builtin_amdgcn_ballot_w64(node < 0);
-			wp.v[WP_ITER]++;
-			if (mn) { wp.v[WP_GROUP]++; wp.v[WP_INBOX] += __popcll(mn); }
-			if (ml) { wp.v[WP_TRI]++; wp.v[WP_MAYBE] += __popcll(ml); }
+			unsigned long long todo = mn;
+			unsigned int distinct = 0;
+			while (todo) {
+				const int first = __builtin_amdgcn_readlane(node, __builtin_ctzll(todo));
+				todo &= ~__builtin_amdgcn_ballot_w64(node == first);
+				distinct++;
+			}
+			if (__builtin_ctzll(act) == (int)__lane_id()) {
+				atomicAdd(&wp.g[20], 1ull);                                   // loop trips
+				if (mn) { atomicAdd(&wp.g[21], 1ull); atomicAdd(&wp.g[22], (unsigned long long)__popcll(mn)); }   // node trips, node lane-visits
+				if (ml) { atomicAdd(&wp.g[23], 1ull); atomicAdd(&wp.g[24], (unsigned long long)__popcll(ml)); }   // leaf trips, leaf lane-visits
+				atomicAdd(&wp.g[25], (unsigned long long)distinct);           // different nodes fetched
+				if (distinct == 1) atomicAdd(&wp.g[26], 1ull);                // node trips with one node for the whole wave
+				if (distinct <= 4 && distinct > 0) atomicAdd(&wp.g[27], 1ull);
+			}
 		}
 #endif
 		if (node >= 0) {
@@ -120,10 +137,22 @@ __device__ __forceinline__ Hit cast_ray_lbvh(const DevScene& sc, int* lds_stack,
 			cswap(key[0], ref[0], key[2], ref[2]);
 			cswap(key[1], ref[1], key[3], ref[3]);
 			cswap(key[1], ref[1], key[2], ref[2]);
-			if (key[3] < inf) push(ref[3]);
-			if (key[2] < inf) push(ref[2]);
-			if (key[1] < inf) push(ref[1]);
-			node = key[0] < inf ? ref[0] : pop();
+			const bool deep = __builtin_amdgcn_ballot_w64(sp > RT_STACK_LDS - 3) != 0ull;
+			if (!deep) {
+				// every lane has room for three entries: store unconditionally, advance only for hits
+				slot0[sp * RT_STACK_PITCH] = ref[3]; sp += key[3] < inf;
+				slot0[sp * RT_STACK_PITCH] = ref[2]; sp += key[2] < inf;
+				slot0[sp * RT_STACK_PITCH] = ref[1]; sp += key[1] < inf;
+				const int top = slot0[(sp > 0 ? sp - 1 : 0) * RT_STACK_PITCH];
+				const bool hit0 = key[0] < inf;
+				node = hit0 ? ref[0] : (sp > 0 ? top : SENT);
+				sp -= (!hit0 && sp > 0);
+			} else {
+				if (key[3] < inf) push_any(ref[3]);
+				if (key[2] < inf) push_any(ref[2]);
+				if (key[1] < inf) push_any(ref[1]);
+				node = key[0] < inf ? ref[0] : pop_any();
+			}
 		} else {
 			const int i = ~node;
 			const float4* T = sc.tri_aos + (size_t)i * 8;
@@ -150,7 +179,14 @@ __device__ __forceinline__ Hit cast_ray_lbvh(const DevScene& sc, int* lds_stack,
 					}
 				}
 			}
-			node = (found && shadow) ? SENT : pop();      // a shadow ray only asks whether a hit with t <= dist exists
+			// a shadow ray only asks whether a hit with t <= dist exists
+			if (__builtin_amdgcn_ballot_w64(sp > RT_STACK_LDS) == 0ull) {
+				const int top = slot0[(sp > 0 ? sp - 1 : 0) * RT_STACK_PITCH];
+				node = ((found && shadow) || sp == 0) ? SENT : top;
+				sp -= sp > 0;
+			} else {
+				node = (found && shadow) ? SENT : pop_any();
+			}
 		}
 	}
 	return h;
