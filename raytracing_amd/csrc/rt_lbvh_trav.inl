@@ -21,6 +21,9 @@
 #define RT_STACK_LDS 16      /* measured: 12-16 beats 24 and 32 (occupancy); deeper paths spill to a private array */
 #endif
 #define RT_STACK_MAX 64
+#ifndef RT_LEAF_MIN
+#define RT_LEAF_MIN 1        /* lanes that must be waiting on a parked leaf before the wave makes a leaf trip */
+#endif
 #define RT_STACK_PITCH 256   /* lanes per workgroup the LDS stack is laid out for */
 
 namespace rt {
@@ -81,12 +84,29 @@ __device__ __forceinline__ Hit cast_ray_lbvh(const DevScene& sc, int* lds_stack,
 		sp++;
 	};
 
+	// pop for a wave whose lanes may or may not all be within the LDS part
+	auto pop = [&]() -> int {
+		if (__builtin_amdgcn_ballot_w64(sp > RT_STACK_LDS) == 0ull) {
+			const int top = slot0[(sp > 0 ? sp - 1 : 0) * RT_STACK_PITCH];
+			const int v = sp > 0 ? top : SENT;
+			sp -= sp > 0;
+			return v;
+		}
+		return pop_any();
+	};
+
 	const float inf = __builtin_huge_valf();
-	while (node != SENT) {
+	// A lane that reaches a leaf parks it in `pend` and keeps walking; the wave tests parked leaves
+	// together once RT_LEAF_MIN lanes cannot go on without it (or nobody has an inner node left), so
+	// a leaf trip serves many lanes.  The order in which a ray meets its triangles does not matter
+	// (see the header), only that all of them are met before the ray finishes.
+	int pend = SENT;
+	while (node != SENT || pend != SENT) {
+		const bool inner = (unsigned int)node < (unsigned int)SENT;
 #ifdef RT_PROFILE
 		if (wp.g) {   // exact wave-level counts (slow: one atomic per event from the first active lane); counters 20..27
 			const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
-			const unsigned long long mn = __builtin_amdgcn_ballot_w64(node >= 0), ml = __builtin_amdgcn_ballot_w64(node < 0);
+			const unsigned long long mn = __builtin_amdgcn_ballot_w64(inner);
 			unsigned long long todo = mn;
 			unsigned int distinct = 0;
 			while (todo) {
@@ -97,14 +117,13 @@ __device__ __forceinline__ Hit cast_ray_lbvh(const DevScene& sc, int* lds_stack,
 			if (__builtin_ctzll(act) == (int)__lane_id()) {
 				atomicAdd(&wp.g[20], 1ull);                                   // loop trips
 				if (mn) { atomicAdd(&wp.g[21], 1ull); atomicAdd(&wp.g[22], (unsigned long long)__popcll(mn)); }   // node trips, node lane-visits
-				if (ml) { atomicAdd(&wp.g[23], 1ull); atomicAdd(&wp.g[24], (unsigned long long)__popcll(ml)); }   // leaf trips, leaf lane-visits
 				atomicAdd(&wp.g[25], (unsigned long long)distinct);           // different nodes fetched
 				if (distinct == 1) atomicAdd(&wp.g[26], 1ull);                // node trips with one node for the whole wave
 				if (distinct <= 4 && distinct > 0) atomicAdd(&wp.g[27], 1ull);
 			}
 		}
 #endif
-		if (node >= 0) {
+		if (inner) {
 			const uint4* nd = sc.bvh4 + (size_t)node * 4;
 			const uint4 w0 = nd[0], w1 = nd[1], w2 = nd[2];
 			const uint2 w3 = *(const uint2*)(nd + 3);
@@ -153,8 +172,20 @@ __device__ __forceinline__ Hit cast_ray_lbvh(const DevScene& sc, int* lds_stack,
 				if (key[1] < inf) push_any(ref[1]);
 				node = key[0] < inf ? ref[0] : pop_any();
 			}
-		} else {
-			const int i = ~node;
+		}
+		if (node < 0 && pend == SENT) { pend = node; node = pop(); }                  // park the leaf, keep walking
+		const bool has = pend != SENT;
+		const bool walking = (unsigned int)node < (unsigned int)SENT;
+		const unsigned long long stuck = __builtin_amdgcn_ballot_w64(has && !walking);
+		const bool leaf_trip = __popcll(stuck) >= RT_LEAF_MIN || (stuck != 0ull && __builtin_amdgcn_ballot_w64(walking) == 0ull);
+#ifdef RT_PROFILE
+		if (wp.g && leaf_trip) {
+			const unsigned long long ml = __builtin_amdgcn_ballot_w64(has);
+			if (__builtin_ctzll(__builtin_amdgcn_ballot_w64(true)) == (int)__lane_id()) { atomicAdd(&wp.g[23], 1ull); atomicAdd(&wp.g[24], (unsigned long long)__popcll(ml)); }
+		}
+#endif
+		if (leaf_trip && has) {
+			const int i = ~pend;
 			const float4* T = sc.tri_aos + (size_t)i * 8;
 			const float4 N4 = T[0], P14 = T[1], P24 = T[2], P34 = T[3], E0 = T[4], E1 = T[5], E2 = T[6];
 			const vec3 nn = xyz(N4), p1 = xyz(P14);
@@ -179,14 +210,9 @@ __device__ __forceinline__ Hit cast_ray_lbvh(const DevScene& sc, int* lds_stack,
 					}
 				}
 			}
-			// a shadow ray only asks whether a hit with t <= dist exists
-			if (__builtin_amdgcn_ballot_w64(sp > RT_STACK_LDS) == 0ull) {
-				const int top = slot0[(sp > 0 ? sp - 1 : 0) * RT_STACK_PITCH];
-				node = ((found && shadow) || sp == 0) ? SENT : top;
-				sp -= sp > 0;
-			} else {
-				node = (found && shadow) ? SENT : pop_any();
-			}
+			pend = SENT;
+			if (found && shadow) { node = SENT; sp = 0; }                                 // a shadow ray only asks whether a hit with t <= dist exists
+			else if (node < 0) { pend = node; node = pop(); }
 		}
 	}
 	return h;
