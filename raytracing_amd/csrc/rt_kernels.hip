@@ -217,10 +217,17 @@ __device__ __forceinline__ Hit cast_ray_pruned(TriPtr tri, int stride, int n, in
 					num = dot(p1 - o, nn);
 				}
 				const float den = dot(d, nn);
+#ifdef RT_PREFILTER_RCP
 				const float r = __builtin_amdgcn_rcpf(den);
 				const float ta = num * r;
 				const bool normal = __builtin_amdgcn_classf(r, 0x108);          // +-normal
 				const bool maybe = !normal || (!(ta < eps_lo) && !(ta > lim_hi));
+#else
+				// eps_lo <= num/den <= lim_hi  <=>  num lies between eps_lo*den and lim_hi*den (either order)
+				const float qa = lim_hi * den, qb = eps_lo * den;
+				const bool normal = __builtin_amdgcn_classf(qb, 0x108);         // +-normal: both products are accurate to 2^-24
+				const bool maybe = !normal || (__builtin_amdgcn_fmed3f(num, qa, qb) == num);
+#endif
 				if (__builtin_amdgcn_ballot_w64(maybe) == 0) continue;
 				RT_PROF(wp, WP_MAYBE);
 				const float t = num / den;                                      // Source.cpp:383
