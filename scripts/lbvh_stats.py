@@ -4,6 +4,8 @@ from raytracing_amd import api, scenes
 desc = scenes.spheres(20, 4, 800, 800)
 with api.Scene.from_desc(desc) as sc:
     t0 = time.time(); sc.commit(0, api.ACCEL_LBVH); print("commit s", time.time() - t0, "build ms", sc.build_ms(0))
+    for rep in range(3):
+        t0 = time.time(); sc.commit(0, api.ACCEL_LBVH); print("re-commit s %.4f build ms %.3f" % (time.time() - t0, sc.build_ms(0)))
     _, st = sc.render_stats(desc.cam_pos, api.camera_trans(desc.cam_rot), desc.width, desc.height, desc.depth, want_frame=False)
 d = st.as_dict(); r = st.rays
 print(d)

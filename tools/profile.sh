@@ -33,3 +33,22 @@ json.dump(summ, open(os.path.join(out, tag + "_room800_pmc.json"), "w"), indent=
 print(json.dumps(summ, indent=1))
 PY
 cat $out/${tag}_room800_kernel_stats.csv
+
+# ---- LBVH workload (config 4): kernel trace + SQ counters ----------------------------------------
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_lbvh -o spheres800 -- python3 bench.py --steps 64 --warmup 16 --no-cpu --workload spheres800 > $out/${tag}_spheres800_bench_under_rocprof.json 2> $out/trace_lbvh.err || exit 1
+cp $out/trace_lbvh/spheres800_kernel_stats.csv $out/${tag}_spheres800_kernel_stats.csv
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $out/pmc_lbvh -o p -- python3 bench.py --steps 32 --warmup 16 --no-cpu --workload spheres800 > /dev/null 2> $out/pmc_lbvh.err || exit 1
+python3 - $out $tag <<'PY'
+import csv, sys, json, collections, os
+out, tag = sys.argv[1], sys.argv[2]
+acc = collections.defaultdict(list)
+for r in csv.DictReader(open(os.path.join(out, "pmc_lbvh", "p_counter_collection.csv"))):
+    if "render_kernel<2, false>" in r["Kernel_Name"]:
+        acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+summ = {k: sum(v) / len(v) for k, v in acc.items()}
+w = summ.get("SQ_WAVES", 1.0)
+summ["per_wave"] = {k: summ[k] / w for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS") if k in summ}
+json.dump(summ, open(os.path.join(out, tag + "_spheres800_pmc.json"), "w"), indent=1)
+print(json.dumps(summ, indent=1))
+PY
+cat $out/${tag}_spheres800_kernel_stats.csv
