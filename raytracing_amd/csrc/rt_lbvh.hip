@@ -199,6 +199,7 @@ __global__ void __launch_bounds__(256) k_collapse4(const float4* __restrict__ no
 	int ref[4];
 	int cnt = 0;
 	const float* nd = (const float*)(nodes + (size_t)i * 4);
+#ifdef RT_COLLAPSE_FIXED
 	for (int side = 0; side < 2; side++) {
 		const int c = __float_as_int(nd[12 + side]);
 		if (c >= 0) {
@@ -212,6 +213,32 @@ __global__ void __launch_bounds__(256) k_collapse4(const float4* __restrict__ no
 			ref[cnt++] = c;
 		}
 	}
+#else
+	// Greedy by surface area: start from the two children, twice replace the inner child with the
+	// largest box by its own two children.  Big children are opened first, so the four boxes a ray
+	// is tested against are of similar size and the node is full whenever the subtree allows.
+	for (int side = 0; side < 2; side++) {
+		for (int k = 0; k < 3; k++) { lo[k][cnt] = nd[side * 6 + k]; hi[k][cnt] = nd[side * 6 + 3 + k]; }
+		ref[cnt++] = __float_as_int(nd[12 + side]);
+	}
+	for (int round = 0; round < 2; round++) {
+		int best = -1;
+		float best_area = -1.0f;
+		for (int c = 0; c < cnt; c++) {
+			if (ref[c] < 0) continue;                                   // a leaf stands for itself
+			const float dx = hi[0][c] - lo[0][c], dy = hi[1][c] - lo[1][c], dz = hi[2][c] - lo[2][c];
+			const float area = dx * dy + dy * dz + dz * dx;
+			if (area > best_area) { best_area = area; best = c; }
+		}
+		if (best < 0) break;
+		const float* cd = (const float*)(nodes + (size_t)ref[best] * 4);
+		for (int k = 0; k < 3; k++) { lo[k][cnt] = cd[6 + k]; hi[k][cnt] = cd[9 + k]; }
+		ref[cnt] = __float_as_int(cd[13]);
+		for (int k = 0; k < 3; k++) { lo[k][best] = cd[k]; hi[k][best] = cd[3 + k]; }
+		ref[best] = __float_as_int(cd[12]);
+		cnt++;
+	}
+#endif
 	for (int c = cnt; c < 4; c++) ref[c] = RT_BVH4_EMPTY;
 	float p[3];
 	unsigned int ql[3], qh[3], eb[3];
