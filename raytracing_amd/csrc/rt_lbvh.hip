@@ -4,10 +4,12 @@
 // north_star replaces that O(N) walk for large scenes by an LBVH built ON the GPU:
 //
 //   1. k_morton      one lane per triangle: centroid of its vertex box, normalised by the scene
-//                    box, 10 bits per axis interleaved to a 30-bit Morton code; key =
-//                    (code << 32) | triangle index, so keys are unique (Karras 2012, §4: "augment
-//                    each key with its index") and equal codes still split into a balanced subtree.
-//   2. radix sort    rocPRIM device radix sort of the 64-bit keys (bits 0..61).
+//                    box, 21 bits per axis interleaved to a 63-bit Morton code; key = (as many
+//                    leading code bits as fit) : (triangle index in ceil(log2 N) bits), 63 bits in
+//                    all, so keys are unique (Karras 2012, §4: "augment each key with its index")
+//                    and equal codes still split into a balanced subtree.  At 100k triangles that
+//                    is 15 code bits per axis.
+//   2. radix sort    rocPRIM device radix sort of the 64-bit keys (the bits in use).
 //   3. k_karras      one lane per internal node i in [0, N-2]: direction, range and split from
 //                    the longest-common-prefix function delta(i, j) = clz(key_i ^ key_j)
 //                    (Karras 2012, Alg. in §3); writes the two child references and the parent
@@ -40,12 +42,13 @@ namespace {
 
 typedef unsigned long long u64;
 
-__device__ __forceinline__ unsigned int expand_bits10(unsigned int v) {
-	// 10 bits -> every third bit of 30
-	v = (v * 0x00010001u) & 0xFF0000FFu;
-	v = (v * 0x00000101u) & 0x0F00F00Fu;
-	v = (v * 0x00000011u) & 0xC30C30C3u;
-	v = (v * 0x00000005u) & 0x49249249u;
+__device__ __forceinline__ u64 expand_bits21(u64 v) {
+	// 21 bits -> every third bit of 63
+	v = (v | (v << 32)) & 0x001f00000000ffffull;
+	v = (v | (v << 16)) & 0x001f0000ff0000ffull;
+	v = (v | (v << 8)) & 0x100f00f00f00f00full;
+	v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+	v = (v | (v << 2)) & 0x1249249249249249ull;
 	return v;
 }
 
@@ -58,21 +61,24 @@ __device__ __forceinline__ void tri_box(const float4* __restrict__ planes, int s
 
 struct BoxF { float lo[3], hi[3]; };
 
-__global__ void __launch_bounds__(256) k_morton(const float4* __restrict__ planes, int stride, int n, BoxF scene, u64* __restrict__ keys) {
+// key = (Morton code, as many leading bits as fit) : (triangle index in `index_bits` bits); 63 bits in all
+__global__ void __launch_bounds__(256) k_morton(const float4* __restrict__ planes, int stride, int n, BoxF scene, int index_bits,
+                                               u64* __restrict__ keys) {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	float lo[3], hi[3];
 	tri_box(planes, stride, i, lo, hi);
-	unsigned int code = 0;
+	u64 code = 0;
 #pragma unroll
 	for (int k = 0; k < 3; k++) {
 		const float ext = scene.hi[k] - scene.lo[k];
 		const float c = 0.5f * (lo[k] + hi[k]);
 		float u = ext > 0.f ? (c - scene.lo[k]) / ext : 0.5f;
-		u = fminf(fmaxf(u * 1024.0f, 0.0f), 1023.0f);
-		code |= expand_bits10((unsigned int)u) << (2 - k);
+		u = fminf(fmaxf(u * 2097152.0f, 0.0f), 2097151.0f);
+		code |= expand_bits21((u64)(unsigned int)u) << (2 - k);
 	}
-	keys[i] = ((u64)code << 32) | (unsigned int)i;
+	const int code_bits = (63 - index_bits) / 3 * 3;                     // whole x/y/z triples
+	keys[i] = ((code >> (63 - code_bits)) << index_bits) | (u64)(unsigned int)i;
 }
 
 // delta(i, j): common-prefix length of keys i and j, -1 outside [0, n)
@@ -81,7 +87,7 @@ __device__ __forceinline__ int delta(const u64* __restrict__ keys, int n, int i,
 	return __clzll((long long)(keys[i] ^ keys[j]));      // keys are unique, the xor is never 0
 }
 
-__global__ void __launch_bounds__(256) k_karras(const u64* __restrict__ keys, int n, float4* __restrict__ nodes,
+__global__ void __launch_bounds__(256) k_karras(const u64* __restrict__ keys, int n, unsigned int index_mask, float4* __restrict__ nodes,
                                                int* __restrict__ parent_int, int* __restrict__ parent_leaf) {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n - 1) return;
@@ -104,8 +110,8 @@ __global__ void __launch_bounds__(256) k_karras(const u64* __restrict__ keys, in
 	} while (t > 1);
 	const int gamma = i + s * d + min(d, 0);
 	const int first = min(i, j), last = max(i, j);
-	const int left = (first == gamma) ? ~(int)(unsigned int)keys[gamma] : gamma;
-	const int right = (last == gamma + 1) ? ~(int)(unsigned int)keys[gamma + 1] : gamma + 1;
+	const int left = (first == gamma) ? ~(int)((unsigned int)keys[gamma] & index_mask) : gamma;
+	const int right = (last == gamma + 1) ? ~(int)((unsigned int)keys[gamma + 1] & index_mask) : gamma + 1;
 	nodes[(size_t)i * 4 + 3] = make_float4(__int_as_float(left), __int_as_float(right), 0.f, 0.f);
 	// parent links: (node << 1) | side
 	if (first == gamma) parent_leaf[gamma] = (i << 1); else parent_int[gamma] = (i << 1);
@@ -124,11 +130,11 @@ __device__ __forceinline__ void store_child_box(float* node, int side, const flo
 }
 
 __global__ void __launch_bounds__(256) k_refit(const float4* __restrict__ planes, int stride, int n, const u64* __restrict__ keys,
-                                              float* __restrict__ nodes, const int* __restrict__ parent_int,
+                                              unsigned int index_mask, float* __restrict__ nodes, const int* __restrict__ parent_int,
                                               const int* __restrict__ parent_leaf, unsigned int* __restrict__ flags, float pad) {
 	const int p = blockIdx.x * blockDim.x + threadIdx.x;
 	if (p >= n) return;
-	const int tri = (int)(unsigned int)keys[p];
+	const int tri = (int)((unsigned int)keys[p] & index_mask);
 	float lo[3], hi[3];
 	tri_box(planes, stride, tri, lo, hi);
 #pragma unroll
@@ -322,7 +328,11 @@ int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 	LB_TRY(dev_alloc(&nodes4, (size_t)(n - 1) * 4));
 	LB_TRY(dev_alloc(&aos, (size_t)n * 8));
 	size_t temp_bytes = 0;
-	LB_HIP(rocprim::radix_sort_keys(nullptr, temp_bytes, keys, keys_sorted, (size_t)n, 0, 62, stream));
+	int index_bits = 1;
+	while (index_bits < 31 && (1ll << index_bits) < (long long)n) index_bits++;
+	const unsigned int index_mask = (unsigned int)((1ull << index_bits) - 1ull);
+	const unsigned int key_bits = (unsigned int)((63 - index_bits) / 3 * 3 + index_bits);
+	LB_HIP(rocprim::radix_sort_keys(nullptr, temp_bytes, keys, keys_sorted, (size_t)n, 0, key_bits, stream));
 	LB_HIP(hipMalloc(&temp, temp_bytes > 0 ? temp_bytes : 16));
 	LB_HIP(hipEventCreate(&e0));
 	LB_HIP(hipEventCreate(&e1));
@@ -336,12 +346,12 @@ int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 	LB_HIP(hipEventRecord(e0, stream));
 	LB_HIP(hipMemsetAsync(flags, 0, (size_t)n * sizeof(unsigned int), stream));
 	LB_HIP(hipMemsetAsync(nodes, 0, (size_t)(n - 1) * 4 * sizeof(float4), stream));
-	hipLaunchKernelGGL(k_morton, dim3(blocks_n), dim3(256), 0, stream, planes, d.stride, n, scene, keys);
+	hipLaunchKernelGGL(k_morton, dim3(blocks_n), dim3(256), 0, stream, planes, d.stride, n, scene, index_bits, keys);
 	LB_HIP(hipGetLastError());
-	LB_HIP(rocprim::radix_sort_keys(temp, temp_bytes, keys, keys_sorted, (size_t)n, 0, 62, stream));
-	hipLaunchKernelGGL(k_karras, dim3(blocks_n), dim3(256), 0, stream, keys_sorted, n, nodes, parent_int, parent_leaf);
+	LB_HIP(rocprim::radix_sort_keys(temp, temp_bytes, keys, keys_sorted, (size_t)n, 0, key_bits, stream));
+	hipLaunchKernelGGL(k_karras, dim3(blocks_n), dim3(256), 0, stream, keys_sorted, n, index_mask, nodes, parent_int, parent_leaf);
 	LB_HIP(hipGetLastError());
-	hipLaunchKernelGGL(k_refit, dim3(blocks_n), dim3(256), 0, stream, planes, d.stride, n, keys_sorted, (float*)nodes,
+	hipLaunchKernelGGL(k_refit, dim3(blocks_n), dim3(256), 0, stream, planes, d.stride, n, keys_sorted, index_mask, (float*)nodes,
 	                   parent_int, parent_leaf, flags, pad);
 	LB_HIP(hipGetLastError());
 	hipLaunchKernelGGL(k_collapse4, dim3(blocks_n), dim3(256), 0, stream, (const float4*)nodes, n - 1, nodes4);
