@@ -170,7 +170,12 @@ int rt_scene_commit(rt_scene* s, int device, int accel_flags) {
 	// (keeps b * inv and o * inv finite for |inv| <= 1e30): rt_kernels.hip cast_ray_pruned.
 	d.far_guard = pad * 1e6f < 1e6f ? pad * 1e6f : 1e6f;
 	if (!(pad * 1e3f <= 1e6f)) d.far_guard = 0.f;
-	try { d.n_clusters = flatten_planes(s->tris, d.stride, pad, planes); } catch (...) { set_error("rt_scene_commit: out of host memory"); return RT_ERR_NOMEM; }
+	try {
+		const PlaneLayout L = flatten_planes(s->tris, d.stride, pad, planes);
+		d.n_clusters = L.n_clusters;
+		d.oct_clusters = L.oct_clusters; d.oct_groups = L.oct_groups;
+		d.oct_cluster_pitch = L.oct_cluster_pitch; d.oct_group_pitch = L.oct_group_pitch;
+	} catch (...) { set_error("rt_scene_commit: out of host memory"); return RT_ERR_NOMEM; }
 	RT_HIP(hipMalloc(&d.planes, planes.size() * sizeof(float)));
 	RT_HIP(hipMemcpy(d.planes, planes.data(), planes.size() * sizeof(float), hipMemcpyHostToDevice));
 	RT_HIP(hipMalloc(&d.lights, (size_t)(nl > 0 ? nl : 1) * 4 * sizeof(float)));

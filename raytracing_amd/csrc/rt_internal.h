@@ -52,6 +52,12 @@ struct DevScene {
 	const float4* tri_aos;     // 8 float4 per triangle (N P1 P2 P3 E0 E1 E2 -): one burst per leaf test
 	int bvh_root;
 	int pad2;
+	// Octant-ordered copies of the group and cluster boxes (brute force): for each of the 8 sign
+	// combinations of a ray direction, entry e is 8 floats (near.xyz, far.xyz, a, b) where near/far
+	// are the box faces a ray of that octant meets first/last per axis; clusters carry a = first
+	// group, b = group count as int bits.  Offsets in floats from `planes`; pitches in entries.
+	long long oct_clusters, oct_groups;
+	int oct_cluster_pitch, oct_group_pitch;
 	// scene bounding box, padded (host: rt_api.cpp scene_box); +-inf when the scene has none
 	float bb_lo[3], bb_hi[3];
 	float far_guard;        // |origin| beyond this: the box tests are switched off for the ray
@@ -99,6 +105,8 @@ struct DeviceState {
 	float far_guard = 0.f;
 	float pad = 0.f;
 	int n_clusters = 0;
+	long long oct_clusters = 0, oct_groups = 0;
+	int oct_cluster_pitch = 0, oct_group_pitch = 0;
 	// scratch framebuffer for rt_render (host output)
 	void* frame = nullptr;
 	size_t frame_bytes = 0;
@@ -126,7 +134,8 @@ int hip_fail(hipError_t e, const char* what);
 void triangle_record(vec3 p1, vec3 p2, vec3 p3, vec3 color, float shin, float* out28);
 void quad_half_record(const float T[3], const float Rdeg[3], const float S[3], const float color[3], float shin, float* out28);
 void camera_trans(const float rot_deg[3], float out16[16]);
-int flatten_planes(const std::vector<float>& tris, int stride, float pad, std::vector<float>& out);   // returns the cluster count
+struct PlaneLayout { int n_clusters; long long oct_clusters, oct_groups; int oct_cluster_pitch, oct_group_pitch; };
+PlaneLayout flatten_planes(const std::vector<float>& tris, int stride, float pad, std::vector<float>& out);
 float scene_box(const std::vector<float>& tris, float lo[3], float hi[3]);   // returns the pad it applied
 
 // rt_kernels.hip

@@ -175,32 +175,70 @@ __device__ __forceinline__ bool slab_hit(float4 lo, float4 hi, vec3 inv, vec3 oi
 // exact path.  (Measured alternatives, kept out: testing all boxes branch-free into a wave mask
 // first, and a straight-line exact path per group, shorten a lone wave's latency but cost
 // instructions and registers; at steady state they are 10-20 % slower than this form.)
-template <bool PRIMARY, typename TriPtr>
-__device__ __forceinline__ Hit cast_ray_pruned(TriPtr tri, int stride, int n, int n_clusters, const float* num0, vec3 o, vec3 d,
+// Wave-uniform scene data is read through the scalar cache (constant address space: the loads
+// become s_load_*, their results live in SGPRs and feed the VALU as scalar operands); the scene is
+// read-only for the lifetime of a launch.
+typedef float v4f __attribute__((ext_vector_type(4)));
+struct c4ptr {
+	const __attribute__((address_space(4))) v4f* p;
+	__device__ __forceinline__ float4 operator[](long long i) const { const v4f v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
+	__device__ __forceinline__ c4ptr offset_floats(long long f) const { c4ptr r; r.p = (const __attribute__((address_space(4))) v4f*)((const __attribute__((address_space(4))) float*)p + f); return r; }
+};
+
+// Slab test against an octant-ordered box record (near.xyz, far.xyz): for a wave whose rays all
+// point into the same octant the near/far faces are known per axis, so the per-axis min/max of
+// slab_hit falls away: 6 fma + max3/max + min3/min + compare.
+__device__ __forceinline__ bool slab_hit_oct(float4 a, float4 b, vec3 inv, vec3 oi, float lim_hi) {
+	const float tmin = fmaxf(fmaxf(__builtin_fmaf(a.x, inv.x, oi.x), __builtin_fmaf(a.y, inv.y, oi.y)),
+	                         fmaxf(__builtin_fmaf(a.z, inv.z, oi.z), 0.0f));
+	const float tmax = fminf(fminf(__builtin_fmaf(a.w, inv.x, oi.x), __builtin_fmaf(b.x, inv.y, oi.y)),
+	                         fminf(__builtin_fmaf(b.y, inv.z, oi.z), lim_hi));
+	return !(tmin > tmax);
+}
+
+// OCT: every live ray of the wave points into octant `oct` (bit k = component k negative).
+template <bool PRIMARY, bool OCT>
+__device__ __forceinline__ Hit cast_ray_pruned(const DevScene& sc, c4ptr tri, int oct, const float* num0, vec3 o, vec3 d,
                                                vec3 inv, vec3 oi, int skip, float lim, bool first_only, WaveProf& wp) {
 	RT_PROF(wp, WP_TRACE);
 	RT_STAMP(wp, 7);        // bounds + slab set-up (since the last outer stamp)
+	const int stride = sc.stride, n = sc.n_tris, n_clusters = sc.n_clusters;
 	Hit h;
 	h.t = 1e9f;
 	h.idx = -1;
 	h.p = make3(0.f, 0.f, 0.f);
 	float lim_hi = lim + fabsf(lim) * RT_PREFILTER_REL;
 	const float eps_lo = RT_EPS_BELOW * (1.0f - RT_PREFILTER_REL);
+	const c4ptr cbox = tri.offset_floats(sc.oct_clusters + (long long)oct * sc.oct_cluster_pitch * 8);
+	const c4ptr gbox = tri.offset_floats(sc.oct_groups + (long long)oct * sc.oct_group_pitch * 8);
 	for (int c = 0; c < n_clusters; c++) {
-		const float4 clo = tri[PL_CLO * stride + c];
-		const float4 chi = tri[PL_CHI * stride + c];
-		const int g0 = __builtin_amdgcn_readfirstlane(__float_as_int(clo.w));
-		const int g1 = g0 + __builtin_amdgcn_readfirstlane(__float_as_int(chi.w));
-		if (g1 - g0 > 1) {
-			// several groups share this box: one test may skip them all
-			RT_PROF(wp, WP_GROUP);
-			if (__builtin_amdgcn_ballot_w64(slab_hit(clo, chi, inv, oi, lim_hi)) == 0) continue;
+		int g0, g1;
+		if constexpr (OCT) {
+			const float4 ca = cbox[2 * c], cb = cbox[2 * c + 1];
+			g0 = __float_as_int(cb.z);
+			g1 = g0 + __float_as_int(cb.w);
+			if (g1 - g0 > 1) {
+				RT_PROF(wp, WP_GROUP);
+				if (__builtin_amdgcn_ballot_w64(slab_hit_oct(ca, cb, inv, oi, lim_hi)) == 0) continue;
+			}
+		} else {
+			const float4 clo = tri[PL_CLO * stride + c];
+			const float4 chi = tri[PL_CHI * stride + c];
+			g0 = __float_as_int(clo.w);
+			g1 = g0 + __float_as_int(chi.w);
+			if (g1 - g0 > 1) {
+				// several groups share this box: one test may skip them all
+				RT_PROF(wp, WP_GROUP);
+				if (__builtin_amdgcn_ballot_w64(slab_hit(clo, chi, inv, oi, lim_hi)) == 0) continue;
+			}
 		}
 		for (int g = g0; g < g1; g++) {
-			const float4 lo = tri[PL_GLO * stride + g];
-			const float4 hi = tri[PL_GHI * stride + g];
 			RT_PROF(wp, WP_GROUP);
-			if (__builtin_amdgcn_ballot_w64(slab_hit(lo, hi, inv, oi, lim_hi)) == 0) continue;
+			if constexpr (OCT) {
+				if (__builtin_amdgcn_ballot_w64(slab_hit_oct(gbox[2 * g], gbox[2 * g + 1], inv, oi, lim_hi)) == 0) continue;
+			} else {
+				if (__builtin_amdgcn_ballot_w64(slab_hit(tri[PL_GLO * stride + g], tri[PL_GHI * stride + g], inv, oi, lim_hi)) == 0) continue;
+			}
 			RT_PROF(wp, WP_INBOX);
 #pragma unroll
 			for (int k = 0; k < RT_GROUP; k++) {
@@ -217,17 +255,10 @@ __device__ __forceinline__ Hit cast_ray_pruned(TriPtr tri, int stride, int n, in
 					num = dot(p1 - o, nn);
 				}
 				const float den = dot(d, nn);
-#ifdef RT_PREFILTER_RCP
-				const float r = __builtin_amdgcn_rcpf(den);
-				const float ta = num * r;
-				const bool normal = __builtin_amdgcn_classf(r, 0x108);          // +-normal
-				const bool maybe = !normal || (!(ta < eps_lo) && !(ta > lim_hi));
-#else
 				// eps_lo <= num/den <= lim_hi  <=>  num lies between eps_lo*den and lim_hi*den (either order)
 				const float qa = lim_hi * den, qb = eps_lo * den;
 				const bool normal = __builtin_amdgcn_classf(qb, 0x108);         // +-normal: both products are accurate to 2^-24
 				const bool maybe = !normal || (__builtin_amdgcn_fmed3f(num, qa, qb) == num);
-#endif
 				if (__builtin_amdgcn_ballot_w64(maybe) == 0) continue;
 				RT_PROF(wp, WP_MAYBE);
 				const float t = num / den;                                      // Source.cpp:383
@@ -375,11 +406,22 @@ __device__ __forceinline__ Hit trace(const DevScene& sc, const float4* lds_tri, 
 		lim = fminf(lim, 1e9f);                                              // (dist == inf -> NaN -> dropped)
 		if (!live) lim = -1.0f;
 		if (!near) { inv = make3(0.f, 0.f, 0.f); oi = make3(0.f, 0.f, 0.f); }   // every box tests as hit
+		// octant of the wave: sign bits of the (clamped) direction; uniform over the live lanes?
+		const unsigned int lane_oct = (__float_as_uint(ds.x) >> 31) | ((__float_as_uint(ds.y) >> 31) << 1) | ((__float_as_uint(ds.z) >> 31) << 2);
+		const unsigned long long lv = __builtin_amdgcn_ballot_w64(live);
+		const int oct = (int)__builtin_amdgcn_readlane(lane_oct, lv ? __builtin_ctzll(lv) : 0);
+		const bool oct_uniform = __builtin_amdgcn_ballot_w64(live && (lane_oct != (unsigned int)oct || !near)) == 0ull;
+		c4ptr tri;
+		tri.p = (const __attribute__((address_space(4))) v4f*)(unsigned long long)sc.planes;
 		if constexpr (ACCEL == 0) {
-			if (all_primary) return cast_ray_pruned<true>(lds_tri, lds_stride, sc.n_tris, sc.n_clusters, lds_num0, o, d, inv, oi, skip, lim, false, wp);
-			return cast_ray_pruned<false>(lds_tri, lds_stride, sc.n_tris, sc.n_clusters, lds_num0, o, d, inv, oi, skip, lim, shadow, wp);
+			if (oct_uniform) {
+				if (all_primary) return cast_ray_pruned<true, true>(sc, tri, oct, lds_num0, o, d, inv, oi, skip, lim, false, wp);
+				return cast_ray_pruned<false, true>(sc, tri, oct, lds_num0, o, d, inv, oi, skip, lim, shadow, wp);
+			}
+			return cast_ray_pruned<false, false>(sc, tri, 0, lds_num0, o, d, inv, oi, skip, lim, shadow, wp);
 		} else {
-			return cast_ray_pruned<false>(sc.planes, sc.stride, sc.n_tris, sc.n_clusters, nullptr, o, d, inv, oi, skip, lim, shadow, wp);
+			if (oct_uniform) return cast_ray_pruned<false, true>(sc, tri, oct, nullptr, o, d, inv, oi, skip, lim, shadow, wp);
+			return cast_ray_pruned<false, false>(sc, tri, 0, nullptr, o, d, inv, oi, skip, lim, shadow, wp);
 		}
 	}
 }
@@ -656,6 +698,8 @@ DevScene dev_scene(const rt_scene* s, const DeviceState& d) {
 	sc.stride = d.stride;
 	sc.n_lights = (int)(s->lights.size() / 4);
 	sc.n_clusters = d.n_clusters;
+	sc.oct_clusters = d.oct_clusters; sc.oct_groups = d.oct_groups;
+	sc.oct_cluster_pitch = d.oct_cluster_pitch; sc.oct_group_pitch = d.oct_group_pitch;
 	sc.bvh_nodes = (const float4*)d.bvh_nodes;
 	sc.bvh4 = (const uint4*)d.bvh4;
 	sc.tri_aos = (const float4*)d.tri_aos;
@@ -699,7 +743,7 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 		const size_t lds = (size_t)RT_STACK_LDS * RT_STACK_PITCH * sizeof(int);   // [entry][lane]
 		if (count) hipLaunchKernelGGL((render_kernel<2, true>), grid, block, lds, stream, sc, fp, tpw);
 		else hipLaunchKernelGGL((render_kernel<2, false>), grid, block, lds, stream, sc, fp, tpw);
-	} else if (sc.n_tris <= RT_LDS_MAX_TRIS) {
+	} else if (sc.n_tris <= RT_LDS_MAX_TRIS && !getenv("RT355_FORCE_GLOBAL")) {
 		const size_t lds = (size_t)lds_stride_of(sc.n_tris) * (PL_COUNT * sizeof(float4) + sizeof(float));
 		if (count) hipLaunchKernelGGL((render_kernel<0, true>), grid, block, lds, stream, sc, fp, tpw);
 		else hipLaunchKernelGGL((render_kernel<0, false>), grid, block, lds, stream, sc, fp, tpw);

@@ -154,7 +154,7 @@ float scene_box(const std::vector<float>& tris, float lo[3], float hi[3]) {
 	return pad;
 }
 
-int flatten_planes(const std::vector<float>& tris, int stride, float pad, std::vector<float>& out) {
+PlaneLayout flatten_planes(const std::vector<float>& tris, int stride, float pad, std::vector<float>& out) {
 	const int n = (int)(tris.size() / RT_TRI_FLOATS);
 	const float inf = __builtin_huge_valf();
 	out.assign((size_t)PL_COUNT * stride * 4, 0.0f);
@@ -222,7 +222,34 @@ int flatten_planes(const std::vector<float>& tris, int stride, float pad, std::v
 		n_clusters++;
 		g += cnt;
 	}
-	return n_clusters;
+	// Octant-ordered copies (rt_internal.h DevScene): one 32-byte record per box and octant, so the
+	// kernel fetches near and far faces with one scalar load and needs no per-axis min/max.
+	// One spare entry per octant lets the kernel prefetch entry e+1 unconditionally.
+	PlaneLayout L;
+	L.n_clusters = n_clusters;
+	L.oct_cluster_pitch = n_clusters + 1;
+	L.oct_group_pitch = n_groups + 1;
+	L.oct_clusters = (long long)out.size();
+	L.oct_groups = L.oct_clusters + 8ll * L.oct_cluster_pitch * 8;
+	out.resize((size_t)(L.oct_groups + 8ll * L.oct_group_pitch * 8), 0.0f);
+	for (int oct = 0; oct < 8; oct++) {
+		auto put = [&](float* q, const float* lo, const float* hi) {
+			for (int k = 0; k < 3; k++) {
+				const bool neg = (oct >> k) & 1;            // bit k: the direction's component k is negative
+				q[k] = neg ? hi[k] : lo[k];
+				q[3 + k] = neg ? lo[k] : hi[k];
+			}
+		};
+		for (int c = 0; c < n_clusters; c++) {
+			float* q = out.data() + L.oct_clusters + ((size_t)oct * L.oct_cluster_pitch + c) * 8;
+			put(q, plane(PL_CLO, c), plane(PL_CHI, c));
+			q[6] = plane(PL_CLO, c)[3];
+			q[7] = plane(PL_CHI, c)[3];
+		}
+		for (int g = 0; g < n_groups; g++)
+			put(out.data() + L.oct_groups + ((size_t)oct * L.oct_group_pitch + g) * 8, plane(PL_GLO, g), plane(PL_GHI, g));
+	}
+	return L;
 }
 
 } // namespace rt
