@@ -385,8 +385,7 @@ __device__ __forceinline__ Hit trace(const DevScene& sc, const float4* lds_tri, 
 		return cast_ray_lbvh<COUNT>(sc, (int*)lds_tri, o, d, skip, live, shadow, dist, lc, wp);
 	} else if constexpr (COUNT) {
 		// instrumented, reference-order loop: the counters follow Source.cpp's own short-circuits
-		if constexpr (ACCEL == 0) return cast_ray_brute<true>(lds_tri, lds_stride, sc.n_tris, o, d, skip, live, lc);
-		else return cast_ray_brute<true>(sc.planes, sc.stride, sc.n_tris, o, d, skip, live, lc);
+		return cast_ray_brute<true>(sc.planes, sc.stride, sc.n_tris, o, d, skip, live, lc);
 	} else {
 		// limit of the search (see cast_ray_pruned); idle lanes get a limit nothing passes
 		// Slab arithmetic t = b * inv - o * inv must stay finite: a direction component below 1e-30
@@ -429,8 +428,7 @@ __device__ __forceinline__ Hit trace(const DevScene& sc, const float4* lds_tri, 
 // Per-lane attribute fetch by hit index (shininess Source.cpp:570/575, normal :561, colour :489).
 template <int ACCEL>
 __device__ __forceinline__ float4 tri_plane(const DevScene& sc, const float4* lds_tri, int lds_stride, int plane, int idx) {
-	if constexpr (ACCEL == 0) return lds_tri[plane * lds_stride + idx];
-	else return sc.planes[plane * sc.stride + idx];
+	return sc.planes[plane * sc.stride + idx];
 }
 
 template <int ACCEL, bool COUNT>
@@ -446,17 +444,13 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : RT_MIN_W
 #endif
 	extern __shared__ float4 s_tri[];
 	const int lds_stride = lds_stride_of(sc.n_tris);
-	float* s_num0 = (float*)(s_tri + PL_COUNT * lds_stride);
+	float* s_num0 = (float*)s_tri;
 	const int frame = fp.n_frames > 1 ? (int)(blockIdx.x / fp.blocks_per_frame) : 0;      // workgroup-uniform
 	const unsigned int block_in_frame = blockIdx.x - (unsigned int)frame * fp.blocks_per_frame;
 	const vec3 cam = make3(fp.cam[frame][0], fp.cam[frame][1], fp.cam[frame][2]);
 	if constexpr (ACCEL == 0) {
-		// stage all planes: consecutive lanes copy consecutive float4 (coalesced 1 KiB per wave op)
-		// (the device planes are zero-padded to a multiple of 64 triangles, so the batch padding reads zeros)
-		for (int k = 0; k < PL_COUNT; k++)
-			for (int i = threadIdx.x; i < lds_stride; i += blockDim.x)
-				s_tri[k * lds_stride + i] = sc.planes[k * sc.stride + i];
-		// numerator of Source.cpp:383 for rays that start at the camera
+		// numerator of Source.cpp:383 for rays that start at the camera: the one per-workgroup table
+		// (the scene itself is read through the scalar cache, see cast_ray_pruned)
 		for (int i = threadIdx.x; i < lds_stride; i += blockDim.x)
 			s_num0[i] = dot(xyz(sc.planes[PL_P1 * sc.stride + i]) - cam, xyz(sc.planes[PL_N * sc.stride + i]));
 		__syncthreads();
@@ -659,12 +653,6 @@ template <int ACCEL>
 __global__ void __launch_bounds__(256) cast_rays_kernel(DevScene sc, int n, const float* __restrict__ rays7, float* __restrict__ out6) {
 	extern __shared__ float4 s_tri[];
 	const int lds_stride = lds_stride_of(sc.n_tris);
-	if constexpr (ACCEL == 0) {
-		for (int k = 0; k < PL_COUNT; k++)
-			for (int i = threadIdx.x; i < lds_stride; i += blockDim.x)
-				s_tri[k * lds_stride + i] = sc.planes[k * sc.stride + i];
-		__syncthreads();
-	}
 	const int r = blockIdx.x * blockDim.x + threadIdx.x;
 	const bool live = r < n;
 	vec3 o = make3(0.f, 0.f, 0.f), d = make3(0.f, 0.f, 1.f);
@@ -744,7 +732,7 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 		if (count) hipLaunchKernelGGL((render_kernel<2, true>), grid, block, lds, stream, sc, fp, tpw);
 		else hipLaunchKernelGGL((render_kernel<2, false>), grid, block, lds, stream, sc, fp, tpw);
 	} else if (sc.n_tris <= RT_LDS_MAX_TRIS && !getenv("RT355_FORCE_GLOBAL")) {
-		const size_t lds = (size_t)lds_stride_of(sc.n_tris) * (PL_COUNT * sizeof(float4) + sizeof(float));
+		const size_t lds = (size_t)lds_stride_of(sc.n_tris) * sizeof(float);
 		if (count) hipLaunchKernelGGL((render_kernel<0, true>), grid, block, lds, stream, sc, fp, tpw);
 		else hipLaunchKernelGGL((render_kernel<0, false>), grid, block, lds, stream, sc, fp, tpw);
 	} else {
@@ -762,7 +750,7 @@ int launch_cast_rays(const DevScene& sc, int accel, int n, const float* d_rays7,
 	if (accel == RT_ACCEL_LBVH) {
 		hipLaunchKernelGGL((cast_rays_kernel<2>), grid, block, (size_t)RT_STACK_LDS * 256 * sizeof(int), stream, sc, n, d_rays7, d_out6);
 	} else if (sc.n_tris <= RT_LDS_MAX_TRIS) {
-		const size_t lds = (size_t)lds_stride_of(sc.n_tris) * (PL_COUNT * sizeof(float4) + sizeof(float));
+		const size_t lds = (size_t)lds_stride_of(sc.n_tris) * sizeof(float);
 		hipLaunchKernelGGL((cast_rays_kernel<0>), grid, block, lds, stream, sc, n, d_rays7, d_out6);
 	} else {
 		hipLaunchKernelGGL((cast_rays_kernel<1>), grid, block, 0, stream, sc, n, d_rays7, d_out6);
