@@ -34,9 +34,9 @@ enum { PL_N = 0, PL_P1, PL_P2, PL_P3, PL_E0, PL_E1, PL_E2, PL_GLO, PL_GHI, PL_CL
 #define RT_GROUP 2
 #endif
 
-// Brute force keeps the whole scene in LDS up to this many triangles ((11 planes x 16 B + 4 B) x
-// 320 = 56.3 KiB, under the 64 KiB a workgroup gets without opting in to more); above it the
-// brute-force kernel reads the planes from global memory / L2 instead.
+// Up to this many triangles the brute-force kernel keeps a per-workgroup LDS table of the primary
+// rays' numerators (rt_kernels.hip, ACCEL 0); forced brute force on larger scenes runs without it
+// (ACCEL 1).  The scene itself is read through the scalar cache in both.
 #define RT_LDS_MAX_TRIS 320
 
 struct DevScene {

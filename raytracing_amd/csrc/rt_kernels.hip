@@ -338,8 +338,12 @@ __device__ __forceinline__ vec3 primary_dir(int x, int y, const FrameParams& fp,
 		v = ((float)y - (float)fp.height * 0.5f) / (float)fp.height;
 		u = ((float)x - (float)fp.width * 0.5f) / (float)fp.width;
 	} else {
-		v = (float)(((double)y - (double)fp.height / 2.0) / (double)(float)fp.height);
-		u = (float)(((double)x - (double)fp.width / 2.0) / (double)(float)fp.width);
+		// (cold: frames of 4M+ pixels a side.  The empty asm keeps the compiler from hoisting the
+		// binary64 halves out of the pixel loop, where they would cost two VGPRs or a spill.)
+		int hh = fp.height, ww = fp.width;
+		asm volatile("" : "+s"(hh), "+s"(ww));
+		v = (float)(((double)y - (double)hh / 2.0) / (double)(float)hh);
+		u = (float)(((double)x - (double)ww / 2.0) / (double)(float)ww);
 	}
 	const float* m = fp.m[frame];
 	vec3 r;
