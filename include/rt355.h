@@ -117,6 +117,47 @@ int rt_scene_accel(const rt_scene* s, int device);
 /* trans = rotate(rotate(I, radians(rot.x), Y), radians(-rot.y), X), column-major 4x4. */
 int rt_camera_trans(const float rot_deg[3], float out_trans16[16]);
 
+/* ---- camera controller (Src:95-212, 237-241, 1294-1295, 1307-1308) -------------------------
+ * The reference's `Camera` as plain data and its frame-loop tail as functions, so that a recorded
+ * or scripted camera path (poses for rt_render_frames_device) moves exactly as the reference's
+ * interactive camera would.  Host arithmetic (binary32, the reference's order; sinf/cosf from libm). */
+typedef struct rt_camera {
+	float position[3];     /* Src:98  */
+	float rotations[3];    /* Src:100, degrees */
+	float direction[3];    /* Src:102, from rotations (Src:126-130) */
+	float right[3], up[3]; /* Src:103-104, set by rt_camera_translate (zero before) */
+	float move_speed;      /* Src:109: moveBaseSpeed = 1/128 until the first frame time */
+	float rot_speed;       /* Src:112: rotBaseSpeed = moveBaseSpeed*3.14159265*2*2 */
+} rt_camera;
+
+/* key flags of Src:237-241 as one mask */
+#define RT_KEY_LEFT        0x001u  /* A      Src:246 */
+#define RT_KEY_RIGHT       0x002u  /* D      Src:247 */
+#define RT_KEY_UP          0x004u  /* SPACE  Src:248 */
+#define RT_KEY_DOWN        0x008u  /* LSHIFT Src:249 */
+#define RT_KEY_FORWARD     0x010u  /* W      Src:250 */
+#define RT_KEY_BACKWARD    0x020u  /* S      Src:251 */
+#define RT_KEY_LOOK_LEFT   0x040u  /* LEFT   Src:253 */
+#define RT_KEY_LOOK_RIGHT  0x080u  /* RIGHT  Src:254 */
+#define RT_KEY_LOOK_UP     0x100u  /* UP     Src:255 */
+#define RT_KEY_LOOK_DOWN   0x200u  /* DOWN   Src:256 */
+
+/* Camera(pos, rot) — Src:132-142 */
+int rt_camera_init(rt_camera* cam, const float pos[3], const float rot_deg[3]);
+/* Camera::rotate(l, r, u, d) — Src:181-209 (pitch clamped to +-89.99) */
+int rt_camera_rotate(rt_camera* cam, int l, int r, int u, int d);
+/* Camera::translate(l, r, u, d, f, b) — Src:144-179 */
+int rt_camera_translate(rt_camera* cam, int l, int r, int u, int d, int f, int b);
+/* moveSpeed = moveBaseSpeed*milis; rotSpeed = rotBaseSpeed*milis — Src:1307-1308 */
+int rt_camera_frame_time(rt_camera* cam, float milis);
+/* The tail of one frame-loop iteration: rotate, translate (Src:1294-1295), frame time (Src:1307-1308). */
+int rt_camera_step(rt_camera* cam, unsigned int key_mask, float milis);
+/* A scripted path: for frame i the pose the frame is drawn with (position -> out_pos3[i],
+ * trans of Src:1145-1147 -> out_trans16[i]) is recorded, then rt_camera_step(key_masks[i],
+ * frame_ms[i]) moves on.  The arrays are what rt_render_frames_device takes. */
+int rt_camera_path(rt_camera* cam, int n_frames, const unsigned int* key_masks, const float* frame_ms,
+                   float* out_pos3, float* out_trans16);
+
 /* ---- render (replaces the getPixelData loop, Src:1248-1264 -> 530-628) --------------------- */
 
 /* Whole frame into HOST memory, synchronous: launch on the scene's device, copy back.

@@ -51,6 +51,8 @@ def lib():
         L.orc_triangle_init.argtypes = [_fp, _fp, _fp, _fp, C.c_float, _fp]
         L.orc_quad_half.argtypes = [_fp, _fp, _fp, _fp, C.c_float, _fp]
         L.orc_camera_trans.argtypes = [_fp, _fp]
+        L.orc_camera_init.argtypes = [_fp, _fp, _fp]
+        L.orc_camera_step.argtypes = [_fp, C.POINTER(C.c_int), C.c_float]
         L.orc_cast_ray.argtypes = [_fp, C.c_int, _fp, _fp, C.c_int, _fp, C.POINTER(Counters)]
         L.orc_cast_ray.restype = C.c_int
         L.orc_render.argtypes = [_fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp,
@@ -92,6 +94,22 @@ def camera_trans(rot_deg) -> np.ndarray:
     out = np.zeros(16, dtype=np.float32)
     r = _f32(rot_deg)
     lib().orc_camera_trans(_p(r), _p(out))
+    return out
+
+
+def camera_run(start6, ms, keys10) -> np.ndarray:
+    """The reference's Camera driven like its frame loop (Src:1294-1295, 1307-1308): per frame the
+    17 state floats after the update + the next frame's trans -> (F, 33)."""
+    cam = np.zeros(17, dtype=np.float32)
+    s = _f32(start6)
+    pos, rot = np.ascontiguousarray(s[:3]), np.ascontiguousarray(s[3:6])
+    lib().orc_camera_init(_p(cam), _p(pos), _p(rot))
+    out = np.zeros((len(ms), 33), dtype=np.float32)
+    for i in range(len(ms)):
+        k = (C.c_int * 10)(*[int(x) for x in keys10[i]])
+        lib().orc_camera_step(_p(cam), k, float(np.float32(ms[i])))
+        out[i, :17] = cam
+        out[i, 17:] = camera_trans(cam[3:6])
     return out
 
 

@@ -24,6 +24,15 @@
 //        rays.f32: K x 7 floats (origin xyz, dir xyz, skip index as float, <0 = NULL)
 //        out.f32 : K x 6 floats (didHit, index of hit triangle or -1, distance, point xyz)
 //
+//   ref_render camera <script.txt> <out.f32>
+//        script: `start px py pz rx ry rz`, then one line per frame `frame ms ll lr lu ld l r u d f b`
+//        (frame time in ms as the loop measures it, Source.cpp:1300; the look and move key flags of
+//        Source.cpp:237-241).  Per frame the reference's own Camera does what the frame loop does
+//        after drawing: rotate, translate (Source.cpp:1294-1295), then the speeds for the next
+//        frame (Source.cpp:1307-1308).
+//        out.f32: per frame 33 floats = position, rotations, direction, right, up, moveSpeed,
+//        rotSpeed after the update, and the `trans` the NEXT frame is drawn with (Source.cpp:1145-1147)
+//
 // When built with -DORACLE_DEPTH_PARAM the Makefile's sed additionally rewrites the literal
 // `int maxBounces = 1;` (Source.cpp:567) to read g_oracle_max_bounces, set by a `depth` line of
 // the scene file; the plain build keeps the literal and rejects depth != 1.
@@ -186,6 +195,39 @@ static int doRays(const char* scenePath, const char* raysPath, const char* outPa
 	return dump(outPath, "", out.data(), out.size()) ? 0 : 4;
 }
 
+static int doCamera(const char* scriptPath, const char* outPath) {
+	FILE* f = fopen(scriptPath, "r");
+	if (!f) { fprintf(stderr, "ref_render: cannot open %s\n", scriptPath); return 2; }
+	Camera camera({ 0, 0, 0 }, { 0, 0, 0 });
+	bool started = false;
+	std::vector<float> out;
+	char line[1024];
+	while (fgets(line, sizeof line, f)) {
+		float v[11];
+		if (sscanf(line, "start %f %f %f %f %f %f", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5]) == 6) {
+			camera = Camera({ v[0], v[1], v[2] }, { v[3], v[4], v[5] });            // Source.cpp:810
+			started = true;
+		} else if (sscanf(line, "frame %f %f %f %f %f %f %f %f %f %f %f", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7], &v[8],
+		                  &v[9], &v[10]) == 11 && started) {
+			float milis = v[0];                                                     // Source.cpp:1075, 1300
+			camera.rotate(v[1] != 0, v[2] != 0, v[3] != 0, v[4] != 0);             // Source.cpp:1294
+			camera.translate(v[5] != 0, v[6] != 0, v[7] != 0, v[8] != 0, v[9] != 0, v[10] != 0);   // Source.cpp:1295
+			camera.moveSpeed = camera.moveBaseSpeed * milis;                        // Source.cpp:1307
+			camera.rotSpeed = camera.rotBaseSpeed * milis;                          // Source.cpp:1308
+			glm::mat4 trans = glm::mat4(1.0f);                                      // Source.cpp:1145-1147
+			trans = glm::rotate(trans, glm::radians((float)camera.rotations.x), glm::vec3(0.0f, 1.0f, 0.0f));
+			trans = glm::rotate(trans, glm::radians(-(float)camera.rotations.y), glm::vec3(1.0f, 0.0f, 0.0f));
+			const glm::vec3* fields[5] = { &camera.position, &camera.rotations, &camera.direction, &camera.right, &camera.up };
+			for (const glm::vec3* p : fields) { out.push_back(p->x); out.push_back(p->y); out.push_back(p->z); }
+			out.push_back(camera.moveSpeed);
+			out.push_back(camera.rotSpeed);
+			for (int k = 0; k < 16; k++) out.push_back(glm::value_ptr(trans)[k]);
+		}
+	}
+	fclose(f);
+	return dump(outPath, "", out.data(), out.size()) ? 0 : 4;
+}
+
 } // namespace oracle_driver
 
 #undef main
@@ -196,6 +238,9 @@ int main(int argc, char** argv) {
 	}
 	if (argc >= 5 && !strcmp(argv[1], "rays")) {
 		return oracle_driver::doRays(argv[2], argv[3], argv[4]);
+	}
+	if (argc >= 4 && !strcmp(argv[1], "camera")) {
+		return oracle_driver::doCamera(argv[2], argv[3]);
 	}
 	fprintf(stderr, "usage: ref_render render <scene.txt> <out_prefix> [repeat]\n       ref_render rays <scene.txt> <rays.f32> <out.f32>\n");
 	return 1;

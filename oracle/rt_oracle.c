@@ -173,6 +173,60 @@ void orc_camera_trans(const float rot_deg[3], float out16[16]) {
 	memcpy(out16, &t, sizeof t);
 }
 
+/* ---- Camera (Src:95-212) and the frame loop's tail (Src:1294-1295, 1307-1308) --------------- */
+
+static v3 cam_direction(float rx_deg, float ry_deg) {
+	/* Src:136-140 == 202-206 */
+	float rx = radiansf(rx_deg), ry = radiansf(ry_deg);
+	v3 d = { sinf(rx) * cosf(ry), sinf(ry), cosf(rx) * cosf(ry) };
+	return normalize3(d);
+}
+
+void orc_camera_init(float c[ORC_CAM_FLOATS], const float pos[3], const float rot_deg[3]) {
+	float move_base = 1 / 128.0f;                                   /* Src:108 */
+	float rot_base = (float)(move_base * 3.14159265 * 2 * 2);       /* Src:111: float * double literal */
+	memset(c, 0, sizeof(float) * ORC_CAM_FLOATS);
+	memcpy(c + 0, pos, sizeof(float) * 3);                          /* Src:133 */
+	memcpy(c + 3, rot_deg, sizeof(float) * 3);                      /* Src:134 */
+	v3 d = cam_direction(rot_deg[0], rot_deg[1]);
+	c[6] = d.x; c[7] = d.y; c[8] = d.z;
+	c[15] = move_base;                                              /* Src:109 */
+	c[16] = rot_base;                                               /* Src:112 */
+}
+
+void orc_camera_step(float c[ORC_CAM_FLOATS], const int k[10], float milis) {
+	float move_base = 1 / 128.0f;
+	float rot_base = (float)(move_base * 3.14159265 * 2 * 2);
+	float rot_speed = c[16], move_speed = c[15];
+	/* rotate(lleft, lright, lup, ldown)  Src:181-209: whole-vector += / -= */
+	float rx = c[3], ry = c[4], rz = c[5];
+	if (k[0]) { rx = rx - rot_speed; ry = ry - 0.0f; rz = rz - 0.0f; }
+	if (k[1]) { rx = rx + rot_speed; ry = ry + 0.0f; rz = rz + 0.0f; }
+	if (k[2]) { rx = rx + 0.0f; ry = ry + rot_speed; rz = rz + 0.0f; }
+	if (k[3]) { rx = rx - 0.0f; ry = ry - rot_speed; rz = rz - 0.0f; }
+	if (ry > 89.99) ry = 89.99;                                     /* Src:195-197: compared and assigned as double literals */
+	if (ry < -89.99) ry = -89.99;                                   /* Src:198-200 */
+	c[3] = rx; c[4] = ry; c[5] = rz;
+	v3 dir = cam_direction(rx, ry);
+	c[6] = dir.x; c[7] = dir.y; c[8] = dir.z;
+	/* translate(left, right, up, down, forward, backward)  Src:144-179 */
+	v3 world_up = { 0.0f, 1.0f, 0.0f };
+	v3 right = normalize3(cross3(world_up, dir));                   /* Src:149 */
+	v3 up = normalize3(cross3(dir, right));                         /* Src:152 */
+	v3 p = { c[0], c[1], c[2] };
+	if (k[4]) p = v3sub(p, v3muls(right, move_speed));
+	if (k[5]) { v3 m = v3muls(right, move_speed); p.x += m.x; p.y += m.y; p.z += m.z; }
+	if (k[6]) { v3 m = v3muls(up, move_speed); p.x += m.x; p.y += m.y; p.z += m.z; }
+	if (k[7]) p = v3sub(p, v3muls(up, move_speed));
+	if (k[8]) { v3 m = v3muls(dir, move_speed); p.x += m.x; p.y += m.y; p.z += m.z; }
+	if (k[9]) p = v3sub(p, v3muls(dir, move_speed));
+	c[0] = p.x; c[1] = p.y; c[2] = p.z;
+	c[9] = right.x; c[10] = right.y; c[11] = right.z;
+	c[12] = up.x; c[13] = up.y; c[14] = up.z;
+	c[15] = move_base * milis;                                      /* Src:1307 */
+	c[16] = rot_base * milis;                                       /* Src:1308 */
+}
+
 /* ---- castRay ----------------------------------------------------------------------------- */
 
 typedef struct {

@@ -45,6 +45,14 @@ void orc_quad_half(const float translate[3], const float rotate_deg[3], const fl
 /* Src:1145-1147  per-frame `trans`; out is column-major like glm::value_ptr */
 void orc_camera_trans(const float rot_deg[3], float out16[16]);
 
+/* Src:95-212 Camera, Src:1294-1295 + 1307-1308 the frame loop's tail.  cam17 = position[3],
+ * rotations[3] (degrees), direction[3], right[3], up[3], moveSpeed, rotSpeed. */
+#define ORC_CAM_FLOATS 17
+void orc_camera_init(float cam17[ORC_CAM_FLOATS], const float pos[3], const float rot_deg[3]);
+/* keys10 = look left, right, up, down (Src:241), move left, right, up, down, forward, backward
+ * (Src:237): rotate, translate, then the speeds from the frame time in ms. */
+void orc_camera_step(float cam17[ORC_CAM_FLOATS], const int keys10[10], float milis);
+
 /* Src:277-405  castRay.  skip < 0 == NULL.  out6 = {didHit, index|-1, distance, point xyz}.
  * Returns didHit. */
 int orc_cast_ray(const float* tris28, int n_tris, const float origin[3], const float dir[3],

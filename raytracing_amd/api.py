@@ -32,7 +32,8 @@ SYMBOLS = (
     "rt_scene_create", "rt_scene_destroy", "rt_scene_clear", "rt_scene_add_triangle",
     "rt_scene_add_triangles", "rt_scene_add_quad_half", "rt_scene_add_light", "rt_scene_load_rto",
     "rt_scene_triangle_count", "rt_scene_light_count", "rt_scene_get_triangles", "rt_scene_commit",
-    "rt_scene_build_ms", "rt_scene_get_bvh", "rt_scene_accel", "rt_camera_trans", "rt_render", "rt_render_device",
+    "rt_scene_build_ms", "rt_scene_get_bvh", "rt_scene_accel", "rt_camera_trans", "rt_camera_init", "rt_camera_rotate",
+    "rt_camera_translate", "rt_camera_frame_time", "rt_camera_step", "rt_camera_path", "rt_render", "rt_render_device",
     "rt_render_frames_device", "rt_render_tiles_device", "rt_shard_rows", "rt_render_stats", "rt_render_multi", "rt_cast_rays",
     "rt_device_count", "rt_set_tiles_per_wave", "rt_last_error", "rt_version",
 )
@@ -42,6 +43,12 @@ class RtError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__("%s (%d): %s" % (ERROR_NAMES.get(code, "RT_ERR"), code, msg))
         self.code = code
+
+
+class CameraState(C.Structure):
+    """rt_camera (rt355.h)."""
+    _fields_ = [("position", C.c_float * 3), ("rotations", C.c_float * 3), ("direction", C.c_float * 3),
+                ("right", C.c_float * 3), ("up", C.c_float * 3), ("move_speed", C.c_float), ("rot_speed", C.c_float)]
 
 
 class Stats(C.Structure):
@@ -117,6 +124,13 @@ def lib():
     L.rt_scene_accel.argtypes = [vp, ci]
     L.rt_scene_get_bvh.argtypes = [vp, ci, _fp, ci]
     L.rt_camera_trans.argtypes = [_fp, _fp]
+    cp = C.POINTER(CameraState)
+    L.rt_camera_init.argtypes = [cp, _fp, _fp]
+    L.rt_camera_rotate.argtypes = [cp, ci, ci, ci, ci]
+    L.rt_camera_translate.argtypes = [cp, ci, ci, ci, ci, ci, ci]
+    L.rt_camera_frame_time.argtypes = [cp, cf]
+    L.rt_camera_step.argtypes = [cp, C.c_uint, cf]
+    L.rt_camera_path.argtypes = [cp, ci, C.POINTER(C.c_uint), _fp, _fp, _fp]
     L.rt_render.argtypes = [vp, _fp, _fp, ci, ci, ci, ci, _fp]
     L.rt_render_device.argtypes = [vp, ci, _fp, _fp, ci, ci, ci, ci, vp, vp]
     L.rt_render_tiles_device.argtypes = [vp, ci, _fp, _fp, ci, ci, ci, ci, ci, ci, ci, vp, vp]
@@ -167,16 +181,61 @@ def shard_rows(height: int, tile_rows: int, tile_first: int, tile_stride: int) -
     return int(lib().rt_shard_rows(height, tile_rows, tile_first, tile_stride))
 
 
+# key flags of Source.cpp:237-241 (rt355.h RT_KEY_*)
+KEY_LEFT, KEY_RIGHT, KEY_UP, KEY_DOWN, KEY_FORWARD, KEY_BACKWARD = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
+KEY_LOOK_LEFT, KEY_LOOK_RIGHT, KEY_LOOK_UP, KEY_LOOK_DOWN = 0x40, 0x80, 0x100, 0x200
+
+
 class Camera:
-    """Camera(position, rotations_deg) — Source.cpp:95-142 (pose only; the WASD controller is
-    outside the render path)."""
+    """Camera(position, rotations_deg) — Source.cpp:95-212: the pose the render takes plus the
+    reference's controller (rotate / translate / frame-time speeds) through rt_camera_*."""
 
     def __init__(self, position=(-5.0, 5.0, 5.0), rotations=(135.0, -45.0, 0.0)):
-        self.position = tuple(float(x) for x in position)
-        self.rotations = tuple(float(x) for x in rotations)
+        self._c = CameraState()
+        p, r = _f32(position), _f32(rotations)
+        _check(lib().rt_camera_init(C.byref(self._c), _p(p), _p(r)))
+
+    position = property(lambda self: tuple(self._c.position))
+    rotations = property(lambda self: tuple(self._c.rotations))
+    direction = property(lambda self: tuple(self._c.direction))
+    right = property(lambda self: tuple(self._c.right))
+    up = property(lambda self: tuple(self._c.up))
+    moveSpeed = property(lambda self: self._c.move_speed)
+    rotSpeed = property(lambda self: self._c.rot_speed)
+
+    def state(self) -> np.ndarray:
+        """position, rotations, direction, right, up, moveSpeed, rotSpeed as 17 float32."""
+        return np.frombuffer(bytes(self._c), dtype=np.float32).copy()
 
     def trans(self) -> np.ndarray:
         return camera_trans(self.rotations)
+
+    def rotate(self, l=False, r=False, u=False, d=False) -> "Camera":                     # Source.cpp:181
+        _check(lib().rt_camera_rotate(C.byref(self._c), int(l), int(r), int(u), int(d)))
+        return self
+
+    def translate(self, l=False, r=False, u=False, d=False, f=False, b=False) -> "Camera":  # Source.cpp:144
+        _check(lib().rt_camera_translate(C.byref(self._c), int(l), int(r), int(u), int(d), int(f), int(b)))
+        return self
+
+    def frame_time(self, milis: float) -> "Camera":                                        # Source.cpp:1307-1308
+        _check(lib().rt_camera_frame_time(C.byref(self._c), float(milis)))
+        return self
+
+    def step(self, key_mask: int, milis: float) -> "Camera":
+        _check(lib().rt_camera_step(C.byref(self._c), int(key_mask), float(milis)))
+        return self
+
+    def path(self, key_masks, frame_ms):
+        """Poses of a scripted path -> (cam_pos (F,3), trans (F,16)) for Scene.render_frames_device."""
+        k = np.ascontiguousarray(np.asarray(key_masks, dtype=np.uint32))
+        ms = _f32(frame_ms)
+        if k.shape != ms.shape or k.ndim != 1:
+            raise ValueError("key_masks and frame_ms must be 1-D and of equal length")
+        pos = np.zeros((len(k), 3), dtype=np.float32)
+        tr = np.zeros((len(k), 16), dtype=np.float32)
+        _check(lib().rt_camera_path(C.byref(self._c), len(k), k.ctypes.data_as(C.POINTER(C.c_uint)), _p(ms), _p(pos), _p(tr)))
+        return pos, tr
 
 
 class Scene:

@@ -376,4 +376,95 @@ int rt_camera_trans(const float rot_deg[3], float out_trans16[16]) {
 	return RT_OK;
 }
 
+// ---- camera controller ----------------------------------------------------------------------
+
+namespace {
+
+vec3 ld(const float* p) { return make3(p[0], p[1], p[2]); }
+void st(float* p, vec3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+
+// Source.cpp:126-130 / 136-140 / 202-206
+vec3 camera_direction(const float rot[3]) {
+	const float rx = radians(rot[0]), ry = radians(rot[1]);
+	return normalize(make3(sinf(rx) * cosf(ry), sinf(ry), cosf(rx) * cosf(ry)));
+}
+
+const float kMoveBaseSpeed = 1 / 128.0f;                                              // Source.cpp:108
+const float kRotBaseSpeed = (float)((double)kMoveBaseSpeed * 3.14159265 * 2 * 2);     // Source.cpp:111 (double expression)
+
+} // namespace
+
+int rt_camera_init(rt_camera* cam, const float pos[3], const float rot_deg[3]) {
+	if (!cam || !pos || !rot_deg) { set_error("rt_camera_init: NULL argument"); return RT_ERR_INVALID; }
+	for (int k = 0; k < 3; k++) { cam->position[k] = pos[k]; cam->rotations[k] = rot_deg[k]; cam->right[k] = 0.f; cam->up[k] = 0.f; }
+	st(cam->direction, camera_direction(cam->rotations));
+	cam->move_speed = kMoveBaseSpeed;          // Source.cpp:109
+	cam->rot_speed = kRotBaseSpeed;            // Source.cpp:112
+	return RT_OK;
+}
+
+int rt_camera_rotate(rt_camera* cam, int l, int r, int u, int d) {
+	if (!cam) { set_error("rt_camera_rotate: NULL argument"); return RT_ERR_INVALID; }
+	vec3 rot = ld(cam->rotations);
+	const float s = cam->rot_speed;
+	if (l) rot = rot - make3(s, 0.f, 0.f);                 // Source.cpp:182-184
+	if (r) rot = rot + make3(s, 0.f, 0.f);                 // Source.cpp:185-187
+	if (u) rot = rot + make3(0.f, s, 0.f);                 // Source.cpp:188-190
+	if (d) rot = rot - make3(0.f, s, 0.f);                 // Source.cpp:191-193
+	if ((double)rot.y > 89.99) rot.y = (float)89.99;       // Source.cpp:195-197 (double literal)
+	if ((double)rot.y < -89.99) rot.y = (float)-89.99;     // Source.cpp:198-200
+	st(cam->rotations, rot);
+	st(cam->direction, camera_direction(cam->rotations));  // Source.cpp:202-206
+	return RT_OK;
+}
+
+int rt_camera_translate(rt_camera* cam, int l, int r, int u, int d, int f, int b) {
+	if (!cam) { set_error("rt_camera_translate: NULL argument"); return RT_ERR_INVALID; }
+	const vec3 world_up = make3(0.f, 1.f, 0.f);            // Source.cpp:107
+	const vec3 dir = ld(cam->direction);
+	const vec3 right = normalize(cross(world_up, dir));    // Source.cpp:149
+	const vec3 up = normalize(cross(dir, right));          // Source.cpp:152
+	vec3 p = ld(cam->position);
+	const float s = cam->move_speed;
+	if (l) p = p - right * s;                              // Source.cpp:158-160
+	if (r) p = p + right * s;
+	if (u) p = p + up * s;
+	if (d) p = p - up * s;
+	if (f) p = p + dir * s;
+	if (b) p = p - dir * s;                                // Source.cpp:173-176
+	st(cam->right, right);
+	st(cam->up, up);
+	st(cam->position, p);
+	return RT_OK;
+}
+
+int rt_camera_frame_time(rt_camera* cam, float milis) {
+	if (!cam) { set_error("rt_camera_frame_time: NULL argument"); return RT_ERR_INVALID; }
+	cam->move_speed = kMoveBaseSpeed * milis;              // Source.cpp:1307
+	cam->rot_speed = kRotBaseSpeed * milis;                // Source.cpp:1308
+	return RT_OK;
+}
+
+int rt_camera_step(rt_camera* cam, unsigned int k, float milis) {
+	if (!cam) { set_error("rt_camera_step: NULL argument"); return RT_ERR_INVALID; }
+	rt_camera_rotate(cam, !!(k & RT_KEY_LOOK_LEFT), !!(k & RT_KEY_LOOK_RIGHT), !!(k & RT_KEY_LOOK_UP), !!(k & RT_KEY_LOOK_DOWN));   // Source.cpp:1294
+	rt_camera_translate(cam, !!(k & RT_KEY_LEFT), !!(k & RT_KEY_RIGHT), !!(k & RT_KEY_UP), !!(k & RT_KEY_DOWN),
+	                    !!(k & RT_KEY_FORWARD), !!(k & RT_KEY_BACKWARD));                                                             // Source.cpp:1295
+	return rt_camera_frame_time(cam, milis);
+}
+
+int rt_camera_path(rt_camera* cam, int n_frames, const unsigned int* key_masks, const float* frame_ms,
+                   float* out_pos3, float* out_trans16) {
+	if (!cam || n_frames < 0 || (n_frames > 0 && (!key_masks || !frame_ms || !out_pos3 || !out_trans16))) {
+		set_error("rt_camera_path: bad argument");
+		return RT_ERR_INVALID;
+	}
+	for (int i = 0; i < n_frames; i++) {
+		for (int k = 0; k < 3; k++) out_pos3[i * 3 + k] = cam->position[k];
+		camera_trans(cam->rotations, out_trans16 + (size_t)i * 16);        // Source.cpp:1145-1147
+		rt_camera_step(cam, key_masks[i], frame_ms[i]);
+	}
+	return RT_OK;
+}
+
 } // extern "C"

@@ -17,7 +17,7 @@ def pytest_configure(config):
 
 
 def golden_cases():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and not f.startswith("rays_"))
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and not f.startswith(("rays_", "camera_")))
 
 
 def load_golden(name):

@@ -12,6 +12,9 @@ scene files written from raytracing_amd/scenes.py, and (3) stores what they prod
                frame   : (H,W,3) float32 — the reference's `data` buffer      (small cases)
                sha256  : sha256 of frame.tobytes() as uint8[32]               (every case)
                q8      : (H,W,3) uint8 — GL-unorm quantised frame             (large cases)
+  camera_path.npz   start (6,), ms (F,), keys (F,10) -> out (F,33): the reference's own Camera
+               (Source.cpp:95-212) driven as the frame loop drives it (rotate, translate, speeds
+               from the frame time), state after every frame + the next frame's `trans`.
   rays_<case>.npz   scene, rays (K,7), out (K,6): the reference's castRay on K hand-made and
                random rays (out = didHit, index, distance, point).
 
@@ -151,11 +154,55 @@ def ray_cases(rng):
     return sc, np.asarray(rays, dtype=np.float32)
 
 
+def camera_case(tmp, index):
+    """Key script for the reference's Camera: random key sets and frame times, long look-up / look-down
+    stretches that run into the +-89.99 pitch clamp, opposite keys together, idle frames."""
+    rng = np.random.default_rng(20251111)
+    start = np.array([-5, 5, 5, 135, -45, 0], dtype=np.float32)
+    ms, keys = [], []
+    for f in range(600):
+        k = (rng.random(10) < 0.25).astype(np.int32)        # look l r u d, move l r u d f b
+        if 100 <= f < 160:
+            k[2], k[3] = 1, 0                                # look up into the clamp
+        if 300 <= f < 380:
+            k[2], k[3] = 0, 1                                # look down into the clamp
+        if f % 97 == 0:
+            k[:] = 0
+        if f % 101 == 0:
+            k[:] = 1
+        ms.append(np.float32(rng.choice([0.35, 4.0, 16.6, 33.3, 194.0, 900.0]) * rng.uniform(0.5, 1.5)))
+        keys.append(k)
+    ms, keys = np.asarray(ms, dtype=np.float32), np.asarray(keys, dtype=np.int32)
+    script = os.path.join(tmp, "camera.txt")
+    with open(script, "w") as fh:
+        fh.write("start " + " ".join("%.9g" % x for x in start) + "\n")
+        for m, k in zip(ms, keys):
+            fh.write("frame %.9g " % m + " ".join(str(int(x)) for x in k) + "\n")
+    out_path = os.path.join(tmp, "camera.f32")
+    subprocess.run([os.path.join(REF, "ref_render"), "camera", script, out_path], check=True)
+    out = np.fromfile(out_path, dtype=np.float32).reshape(-1, 33)
+    assert out.shape[0] == len(ms)
+    path = os.path.join(HERE, "camera_path.npz")
+    np.savez_compressed(path, start=start, ms=ms, keys=keys, out=out)
+    index["camera_path"] = dict(frames=int(len(ms)), clamped_frames=int((np.abs(out[:, 4]) > 89.98).sum()),
+                                bytes=os.path.getsize(path))
+    print("camera_path: %d frames, %d at the pitch clamp" % (len(ms), index["camera_path"]["clamped_frames"]))
+
+
 def main():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
     rng = np.random.default_rng(20251110)
+    if "--camera-only" in sys.argv:
+        index = json.load(open(os.path.join(HERE, "INDEX.json")))
+        with tempfile.TemporaryDirectory() as tmp:
+            camera_case(tmp, index)
+        with open(os.path.join(HERE, "INDEX.json"), "w") as f:
+            json.dump(index, f, indent=1, sort_keys=True)
+            f.write("\n")
+        return
     index = {}
     with tempfile.TemporaryDirectory() as tmp:
+        camera_case(tmp, index)
         for name, sc in cases():
             text, tris, trans, frame, info = run_ref(sc, tmp)
             digest = hashlib.sha256(frame.tobytes()).digest()

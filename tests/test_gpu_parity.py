@@ -175,6 +175,31 @@ def test_frame_batch_equals_single_frames():
     assert not np.array_equal(singles[0], singles[19])
 
 
+def test_controller_path_frames_vs_oracle(oracle):
+    """A key-scripted walk of the reference's camera (rt_camera_path, Source.cpp:144-209, 1294-1308)
+    rendered in one launch: every frame equals the oracle's frame for that pose."""
+    import torch
+    desc = scenes.room(72, 56)
+    K = api
+    script = [K.KEY_FORWARD, K.KEY_FORWARD | K.KEY_LOOK_LEFT, K.KEY_LOOK_UP | K.KEY_RIGHT, K.KEY_LOOK_UP | K.KEY_UP,
+              K.KEY_BACKWARD | K.KEY_LOOK_RIGHT, K.KEY_LOOK_DOWN | K.KEY_LEFT | K.KEY_DOWN, 0, K.KEY_FORWARD]
+    ms = [16.6, 33.3, 194.0, 500.0, 8.0, 250.0, 16.6, 16.6]
+    pos, tr = api.Camera(desc.cam_pos, desc.cam_rot).path(script, ms)
+    assert len({tuple(p) for p in pos}) >= 6
+    tris, lights = oracle.build_scene(desc)
+    n = desc.width * desc.height * 3
+    with api.Scene.from_desc(desc) as sc:
+        sc.commit(0)
+        buf = torch.empty((len(script) * n,), dtype=torch.float32, device="cuda:0")
+        sc.render_frames_device(0, pos, tr, desc.width, desc.height, desc.depth, api.STRICT, buf.data_ptr(), n,
+                                torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = buf.cpu().numpy().reshape(len(script), desc.height, desc.width, 3)
+    for i in range(len(script)):
+        want = oracle.render(tris, lights, pos[i], tr[i], desc.width, desc.height, desc.depth)
+        assert np.array_equal(_bits(got[i]), _bits(want)), i
+
+
 def _soup(seed, n, extent, w=96, h=64, depth=3, lights=3, cam=None, needles=False):
     """Random triangle soup (nothing like the reference's room): arbitrary orientations, sizes
     from slivers to scene-sized, mirrors, several lights — the inputs on which the work-skipping
