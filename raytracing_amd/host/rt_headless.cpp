@@ -15,6 +15,12 @@
 //   rt_headless [--scene stock|FILE] [--size W H] [--depth D] [--camera px py pz rx ry rz]
 //               [--frames N] [--fast] [--lbvh|--brute] [--device K]
 //               [--txt Image.txt] [--ppm out.ppm] [--raw out.f32] [--rto model.rto]
+//               [--walk SCRIPT]
+//
+// --walk drives the camera as the reference's frame loop does (Source.cpp:1294-1295, 1307-1308):
+// SCRIPT has one line per frame, `frame ms ll lr lu ld l r u d f b` (frame time in ms, then the look
+// and move key flags of Source.cpp:237-241; the format oracle/_ref's `camera` mode reads); each frame
+// is drawn with the current pose, then rt_camera_step moves on.  The last frame drawn is dumped.
 //
 // FILE uses the text format of oracle/SCENE_FORMAT.md.  No CPU rendering happens here.
 #include <chrono>
@@ -40,7 +46,7 @@ struct Options {
 	int mode = RT_RENDER_STRICT;
 	int accel = RT_ACCEL_AUTO;
 	int device = 0;
-	std::string txt, ppm, raw, rto;
+	std::string txt, ppm, raw, rto, walk;
 };
 
 int fail(const char* what) {
@@ -152,6 +158,7 @@ int main(int argc, char** argv) {
 		else if (a == "--ppm") { need(1); o.ppm = argv[++i]; }
 		else if (a == "--raw") { need(1); o.raw = argv[++i]; }
 		else if (a == "--rto") { need(1); o.rto = argv[++i]; }
+		else if (a == "--walk") { need(1); o.walk = argv[++i]; }
 		else { fprintf(stderr, "rt_headless: unknown option %s (see the header of rt_headless.cpp)\n", a.c_str()); return 2; }
 	}
 	rt_scene* s = rt_scene_create();
@@ -161,8 +168,32 @@ int main(int argc, char** argv) {
 	if (!o.rto.empty() && rt_scene_load_rto(s, o.rto.c_str()) < 0) { fail("loadModel"); rt_scene_destroy(s); return 1; }
 	if (rt_scene_commit(s, o.device, o.accel) != RT_OK) { fail("rt_scene_commit"); rt_scene_destroy(s); return 1; }
 
+	// key script (optional): one entry per frame
+	std::vector<unsigned int> keys;
+	std::vector<float> key_ms;
+	if (!o.walk.empty()) {
+		FILE* f = fopen(o.walk.c_str(), "r");
+		if (!f) { fprintf(stderr, "rt_headless: cannot open %s\n", o.walk.c_str()); rt_scene_destroy(s); return 1; }
+		char line[512];
+		while (fgets(line, sizeof line, f)) {
+			float ms;
+			int k[10];
+			if (sscanf(line, "frame %f %d %d %d %d %d %d %d %d %d %d", &ms, &k[0], &k[1], &k[2], &k[3], &k[4], &k[5], &k[6], &k[7], &k[8], &k[9]) != 11) continue;
+			const unsigned int bit[10] = { RT_KEY_LOOK_LEFT, RT_KEY_LOOK_RIGHT, RT_KEY_LOOK_UP, RT_KEY_LOOK_DOWN, RT_KEY_LEFT, RT_KEY_RIGHT,
+			                               RT_KEY_UP, RT_KEY_DOWN, RT_KEY_FORWARD, RT_KEY_BACKWARD };
+			unsigned int m = 0;
+			for (int j = 0; j < 10; j++) if (k[j]) m |= bit[j];
+			keys.push_back(m);
+			key_ms.push_back(ms);
+		}
+		fclose(f);
+		if (keys.empty()) { fprintf(stderr, "rt_headless: %s holds no `frame` line\n", o.walk.c_str()); rt_scene_destroy(s); return 1; }
+		o.frames = (int)keys.size();
+	}
+
+	rt_camera camera;
+	rt_camera_init(&camera, o.cam, o.cam + 3);                          // Source.cpp:810
 	float trans[16];
-	rt_camera_trans(o.cam + 3, trans);                                  // Source.cpp:1145-1147
 	std::vector<float> data((size_t)o.width * o.height * 3);            // Source.cpp:1035
 	float build_ms = 0;
 	rt_scene_build_ms(s, o.device, &build_ms);
@@ -170,11 +201,16 @@ int main(int argc, char** argv) {
 	       rt_scene_accel(s, o.device) == RT_ACCEL_LBVH ? "lbvh" : "brute", build_ms);
 	for (int f = 0; f < o.frames; f++) {
 		auto t0 = std::chrono::steady_clock::now();                     // Source.cpp:1129
-		if (rt_render(s, o.cam, trans, o.width, o.height, o.depth, o.mode, data.data()) != RT_OK) { fail("rt_render"); rt_scene_destroy(s); return 1; }
+		rt_camera_trans(camera.rotations, trans);                       // Source.cpp:1145-1147
+		if (rt_render(s, camera.position, trans, o.width, o.height, o.depth, o.mode, data.data()) != RT_OK) { fail("rt_render"); rt_scene_destroy(s); return 1; }
+		if (!keys.empty()) rt_camera_step(&camera, keys[f], key_ms[f]); // Source.cpp:1294-1295, 1307-1308 (scripted frame time)
 		auto t1 = std::chrono::steady_clock::now();
 		double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
 		printf("%f ms %f FPS\n", ms, 1000.0 / ms);                      // Source.cpp:1301
 	}
+	if (!keys.empty())
+		printf("camera after the walk: position %.9g %.9g %.9g rotations %.9g %.9g %.9g\n", camera.position[0], camera.position[1],
+		       camera.position[2], camera.rotations[0], camera.rotations[1], camera.rotations[2]);
 	bool ok = true;
 	if (!o.txt.empty()) ok = write_image(o.txt, data, o.width, o.height, true) && ok;
 	if (!o.ppm.empty()) ok = write_image(o.ppm, data, o.width, o.height, false) && ok;

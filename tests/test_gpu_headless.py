@@ -1,0 +1,53 @@
+"""The C++ headless harness (raytracing_amd/host/rt_headless, links only the C ABI): the stand-in
+for the reference's main() renders a scene file along a key-scripted camera walk
+(Source.cpp:1126-1310 without the viewer) and dumps the last frame; it must equal the oracle's
+frame for the pose the reference's camera has at that point."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from raytracing_amd import api, scenes
+
+pytestmark = pytest.mark.gpu
+EXE = os.path.join(ROOT, "raytracing_amd", "host", "rt_headless")
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def test_headless_walk_equals_oracle(tmp_path, oracle):
+    assert os.path.exists(EXE), "build raytracing_amd/host first (__graft_entry__.build)"
+    desc = scenes.room(96, 64)
+    scene = tmp_path / "scene.txt"
+    scene.write_text(desc.to_text())
+    frames = [(16.6, [0, 0, 0, 0, 0, 0, 0, 0, 1, 0]), (33.3, [1, 0, 0, 0, 0, 0, 0, 0, 1, 0]), (250.0, [0, 0, 1, 0, 0, 1, 1, 0, 0, 0]),
+              (100.0, [0, 1, 0, 1, 1, 0, 0, 0, 0, 1]), (16.6, [0] * 10)]
+    walk = tmp_path / "walk.txt"
+    walk.write_text("".join("frame %.9g %s\n" % (ms, " ".join(map(str, k))) for ms, k in frames))
+    raw, txt = tmp_path / "out.f32", tmp_path / "Image.txt"
+    res = subprocess.run([EXE, "--scene", str(scene), "--walk", str(walk), "--raw", str(raw), "--txt", str(txt)],
+                         capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    assert res.stdout.count(" FPS") == len(frames)
+    got = np.fromfile(raw, dtype=np.float32).reshape(desc.height, desc.width, 3)
+
+    # the pose of the LAST frame drawn: four steps from the scene's camera
+    cam = api.Camera(desc.cam_pos, desc.cam_rot)
+    bits = [api.KEY_LOOK_LEFT, api.KEY_LOOK_RIGHT, api.KEY_LOOK_UP, api.KEY_LOOK_DOWN, api.KEY_LEFT, api.KEY_RIGHT,
+            api.KEY_UP, api.KEY_DOWN, api.KEY_FORWARD, api.KEY_BACKWARD]
+    for ms, k in frames[:-1]:
+        cam.step(sum(b for b, on in zip(bits, k) if on), ms)
+    tris, lights = oracle.build_scene(desc)
+    want = oracle.render(tris, lights, cam.position, cam.trans(), desc.width, desc.height, desc.depth)
+    assert np.array_equal(_bits(got), _bits(want))
+    assert not np.array_equal(_bits(want), _bits(oracle.render_desc(desc)))      # the camera really moved
+
+    # Image.txt: P3, top row first, GL unorm quantisation
+    tok = txt.read_text().split()
+    assert tok[:4] == ["P3", str(desc.width), str(desc.height), "255"]
+    px = np.array(tok[4:], dtype=np.int64).reshape(desc.height, desc.width, 3)
+    assert np.array_equal(px[::-1], oracle.quantize(want).astype(np.int64))
