@@ -437,3 +437,24 @@ def quantize(rgb: np.ndarray) -> np.ndarray:
     c = np.where(c > 0, c, np.float32(0))          # NaN and negatives -> 0
     c = np.minimum(c, np.float32(1))
     return (c * np.float32(255.0) + np.float32(0.5)).astype(np.int32).astype(np.uint8)
+
+
+def frame_diff(a: np.ndarray, b: np.ndarray) -> dict:
+    """The north_star comparison of two frames (float (H,W,3) or already 8-bit): per 8-bit channel
+    differences after the GL unorm rule, pixels beyond 1 LSB, and hit/miss flips (a pixel that is
+    black — the reference's miss colour, Source.cpp:623-625 — in exactly one of the two)."""
+    qa = a if a.dtype == np.uint8 else quantize(a)
+    qb = b if b.dtype == np.uint8 else quantize(b)
+    if qa.shape != qb.shape or qa.ndim != 3 or qa.shape[2] != 3:
+        raise ValueError("frame_diff wants two (H,W,3) frames of one size")
+    d = np.abs(qa.astype(np.int16) - qb.astype(np.int16)).max(axis=2)
+    black_a, black_b = ~qa.any(axis=2), ~qb.any(axis=2)
+    n = d.size
+    over = int((d > 1).sum())
+    out = dict(pixels=n, differing=int((d > 0).sum()), over_1_lsb=over, max_lsb=int(d.max()) if n else 0,
+               flips=int((black_a != black_b).sum()), within_1_lsb_fraction=float(1.0 - over / n) if n else 1.0)
+    out["meets_north_star"] = out["within_1_lsb_fraction"] >= 0.999
+    if a.dtype != np.uint8 and b.dtype != np.uint8:
+        fa, fb = np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32)
+        out["bit_identical"] = bool(np.array_equal(fa.view(np.uint32), fb.view(np.uint32)))
+    return out

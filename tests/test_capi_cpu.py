@@ -107,3 +107,32 @@ def test_quantize_matches_oracle(oracle):
     assert np.array_equal(api.quantize(x), oracle.quantize(x))
     r = np.random.default_rng(1).random(10000, dtype=np.float32) * 1.2 - 0.1
     assert np.array_equal(api.quantize(r), oracle.quantize(r))
+
+
+def test_frame_diff_and_imgdiff_tool(tmp_path):
+    """the comparison north_star asks for (<= 1 LSB on >= 99.9 % of pixels, flips counted)."""
+    import json
+    import subprocess
+    import sys
+    rng = np.random.default_rng(5)
+    a = rng.uniform(0.1, 1.0, (40, 50, 3)).astype(np.float32)
+    b = a.copy()
+    r = api.frame_diff(a, b)
+    assert r["bit_identical"] and r["differing"] == 0 and r["flips"] == 0 and r["meets_north_star"]
+    b[3, 4] = 0.0                       # one hit -> miss flip
+    b[5, 6, 1] += 2.5 / 255.0           # one pixel 2-3 LSB off
+    b[7, 8, 2] += 1.0 / 255.0           # one pixel about 1 LSB off
+    r = api.frame_diff(a, b)
+    assert not r["bit_identical"] and r["flips"] == 1 and r["over_1_lsb"] == 2 and r["differing"] == 3
+    assert r["pixels"] == 2000 and r["meets_north_star"] == (1 - 2 / 2000 >= 0.999)
+    # the command-line tool on a raw dump and a P6 image of the same frame
+    raw = tmp_path / "a.f32"
+    a.tofile(raw)
+    ppm = tmp_path / "b.ppm"
+    with open(ppm, "wb") as f:
+        f.write(b"P6\n50 40\n255\n" + api.quantize(b)[::-1].tobytes())
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "imgdiff.py"), str(raw), str(ppm), "--size", "50", "40"],
+                         capture_output=True, text=True)
+    out = json.loads(res.stdout)
+    assert out["flips"] == 1 and out["over_1_lsb"] == 2
+    assert res.returncode == (0 if out["meets_north_star"] else 1)
