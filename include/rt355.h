@@ -43,8 +43,8 @@ extern "C" {
 /* rt_render* flags */
 #define RT_RENDER_STRICT 0   /* unfused IEEE binary32 in the reference's operation order:
                                 bit-identical frames                                         */
-#define RT_RENDER_FAST   1   /* FMA-contracted, algebraically regrouped edge tests: hit/miss
-                                may flip on grazing edges (tolerance: <=1 LSB on >=99.9 % px) */
+#define RT_RENDER_FAST   1   /* reserved for a tolerance-bound variant; today it runs the strict
+                                kernels (a contracted build measured 2-5 % faster: DESIGN.md 3) */
 
 /* One triangle record as the reference stores it (Src:31-43), 28 floats:
  * p[3] n[3] p1[3] p2[3] p3[3] edge0[3] edge1[3] edge2[3] color[3] shininess */
