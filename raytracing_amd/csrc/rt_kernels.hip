@@ -735,7 +735,7 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 		const size_t lds = (size_t)RT_STACK_LDS * RT_STACK_PITCH * sizeof(int);   // [entry][lane]
 		if (count) hipLaunchKernelGGL((render_kernel<2, true>), grid, block, lds, stream, sc, fp, tpw);
 		else hipLaunchKernelGGL((render_kernel<2, false>), grid, block, lds, stream, sc, fp, tpw);
-	} else if (sc.n_tris <= RT_LDS_MAX_TRIS && !getenv("RT355_FORCE_GLOBAL")) {
+	} else if (sc.n_tris <= RT_LDS_MAX_TRIS) {
 		const size_t lds = (size_t)lds_stride_of(sc.n_tris) * sizeof(float);
 		if (count) hipLaunchKernelGGL((render_kernel<0, true>), grid, block, lds, stream, sc, fp, tpw);
 		else hipLaunchKernelGGL((render_kernel<0, false>), grid, block, lds, stream, sc, fp, tpw);
