@@ -170,8 +170,15 @@ int rt_scene_commit(rt_scene* s, int device, int accel_flags) {
 	// (keeps b * inv and o * inv finite for |inv| <= 1e30): rt_kernels.hip cast_ray_pruned.
 	d.far_guard = pad * 1e6f < 1e6f ? pad * 1e6f : 1e6f;
 	if (!(pad * 1e3f <= 1e6f)) d.far_guard = 0.f;
+	// acceleration structure: decided before the upload, because only brute force needs the
+	// octant-ordered box records (128 B per triangle)
+	d.accel = accel_flags == RT_ACCEL_AUTO ? (n > RT_BRUTE_AUTO_MAX ? RT_ACCEL_LBVH : RT_ACCEL_BRUTE) : accel_flags;
+	if (d.accel == RT_ACCEL_LBVH && n < 2) d.accel = RT_ACCEL_BRUTE;    // a tree needs two leaves
+	bool box_finite = true;
+	for (int k = 0; k < 3; k++) box_finite = box_finite && (d.bb_hi[k] - d.bb_lo[k] < __builtin_huge_valf());
+	if (d.accel == RT_ACCEL_LBVH && accel_flags == RT_ACCEL_AUTO && !box_finite) d.accel = RT_ACCEL_BRUTE;   // a non-finite vertex
 	try {
-		const PlaneLayout L = flatten_planes(s->tris, d.stride, pad, planes);
+		const PlaneLayout L = flatten_planes(s->tris, d.stride, pad, d.accel == RT_ACCEL_BRUTE, planes);
 		d.n_clusters = L.n_clusters;
 		d.oct_clusters = L.oct_clusters; d.oct_groups = L.oct_groups;
 		d.oct_cluster_pitch = L.oct_cluster_pitch; d.oct_group_pitch = L.oct_group_pitch;
@@ -181,13 +188,10 @@ int rt_scene_commit(rt_scene* s, int device, int accel_flags) {
 	RT_HIP(hipMalloc(&d.lights, (size_t)(nl > 0 ? nl : 1) * 4 * sizeof(float)));
 	if (nl > 0) RT_HIP(hipMemcpy(d.lights, s->lights.data(), (size_t)nl * 4 * sizeof(float), hipMemcpyHostToDevice));
 	RT_HIP(hipMalloc(&d.counters, 32 * sizeof(unsigned long long)));
-	d.accel = accel_flags == RT_ACCEL_AUTO ? (n > RT_BRUTE_AUTO_MAX ? RT_ACCEL_LBVH : RT_ACCEL_BRUTE) : accel_flags;
-	if (d.accel == RT_ACCEL_LBVH && n < 2) d.accel = RT_ACCEL_BRUTE;    // a tree needs two leaves
 	d.build_ms = 0.f;
 	if (d.accel == RT_ACCEL_LBVH) {
 		int rc = lbvh_build(s, d, nullptr);
-		if (rc == RT_ERR_LIMIT && accel_flags == RT_ACCEL_AUTO) d.accel = RT_ACCEL_BRUTE;   // e.g. a non-finite vertex
-		else if (rc != RT_OK) return rc;
+		if (rc != RT_OK) return rc;
 	}
 	d.valid = true;
 	if (s->first_device < 0 || !s->dev.count(s->first_device) || !s->dev[s->first_device].valid) s->first_device = device;

@@ -135,7 +135,7 @@ void triangle_record(vec3 p1, vec3 p2, vec3 p3, vec3 color, float shin, float* o
 void quad_half_record(const float T[3], const float Rdeg[3], const float S[3], const float color[3], float shin, float* out28);
 void camera_trans(const float rot_deg[3], float out16[16]);
 struct PlaneLayout { int n_clusters; long long oct_clusters, oct_groups; int oct_cluster_pitch, oct_group_pitch; };
-PlaneLayout flatten_planes(const std::vector<float>& tris, int stride, float pad, std::vector<float>& out);
+PlaneLayout flatten_planes(const std::vector<float>& tris, int stride, float pad, bool with_octant_records, std::vector<float>& out);
 float scene_box(const std::vector<float>& tris, float lo[3], float hi[3]);   // returns the pad it applied
 
 // rt_kernels.hip

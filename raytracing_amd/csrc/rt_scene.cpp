@@ -154,7 +154,7 @@ float scene_box(const std::vector<float>& tris, float lo[3], float hi[3]) {
 	return pad;
 }
 
-PlaneLayout flatten_planes(const std::vector<float>& tris, int stride, float pad, std::vector<float>& out) {
+PlaneLayout flatten_planes(const std::vector<float>& tris, int stride, float pad, bool with_octant_records, std::vector<float>& out) {
 	const int n = (int)(tris.size() / RT_TRI_FLOATS);
 	const float inf = __builtin_huge_valf();
 	out.assign((size_t)PL_COUNT * stride * 4, 0.0f);
@@ -227,6 +227,11 @@ PlaneLayout flatten_planes(const std::vector<float>& tris, int stride, float pad
 	// One spare entry per octant lets the kernel prefetch entry e+1 unconditionally.
 	PlaneLayout L;
 	L.n_clusters = n_clusters;
+	if (!with_octant_records) {        // LBVH commits: the brute-force loop is never run on them
+		L.oct_clusters = L.oct_groups = 0;
+		L.oct_cluster_pitch = L.oct_group_pitch = 0;
+		return L;
+	}
 	L.oct_cluster_pitch = n_clusters + 1;
 	L.oct_group_pitch = n_groups + 1;
 	L.oct_clusters = (long long)out.size();
