@@ -703,15 +703,15 @@ DevScene dev_scene(const rt_scene* s, const DeviceState& d) {
 	return sc;
 }
 
-static int pick_tiles_per_wave(long long tiles) {
-	// One 8x8 tile per wave until a launch has more than ~128k waves (16 per wave slot of the
-	// chip); measured on the depth-16 mirror scene at 4K, longer tile runs only pay once the
-	// launch is that large — below it they cost balance at the tail.
-	const long long target_waves = 128 * 1024;
-	long long tpw = tiles / target_waves;
-	if (tpw < 1) tpw = 1;
-	if (tpw > 16) tpw = 16;
-	return (int)tpw;
+static int pick_tiles_per_wave(int accel, long long tiles) {
+	// 8x8 tiles per wavefront.  Measured: with two tiles a lane that finishes its pixel
+	// early (a miss, a matte hit next to a 16-bounce mirror path) takes the next pixel instead of
+	// idling — brute force gains 4 % on the room and stock scenes and the depth-16 mirror scene is at
+	// its best (373 us against 386 with one tile, 412 with 16); longer runs only add imbalance at the
+	// tail of the launch.  The LBVH kernel is best with one (its lanes are refilled less usefully:
+	// 93 against 101 us), and so are launches too small to fill the chip twice over.
+	if (accel == RT_ACCEL_LBVH) return 1;
+	return tiles >= 4 * 8192 ? 2 : 1;          // 8192 wave slots on 256 CUs
 }
 
 int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int render_flags, bool count, hipStream_t stream) {
@@ -721,7 +721,7 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 	const int n_frames = fp.n_frames < 1 ? 1 : fp.n_frames;
 	const long long tiles = (long long)((fp.width + 7) / 8) * ((fp.local_rows + 7) / 8);
 	if (tiles * 64 > 0xf0000000LL) { set_error("rt_render: %dx%d needs more than 2^32 work items", fp.width, fp.local_rows); return RT_ERR_LIMIT; }
-	int tpw = fp.tiles_per_wave > 0 ? fp.tiles_per_wave : pick_tiles_per_wave(tiles * n_frames);
+	int tpw = fp.tiles_per_wave > 0 ? fp.tiles_per_wave : pick_tiles_per_wave(accel, tiles * n_frames);
 	const long long waves = (tiles + tpw - 1) / tpw;
 	static const int env_block = [] { const char* e = getenv("RT355_BLOCK_THREADS"); int v = e ? atoi(e) : 0; return (v == 64 || v == 128 || v == 256) ? v : 0; }();
 	const int threads = env_block ? env_block : 256;
