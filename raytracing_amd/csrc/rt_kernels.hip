@@ -440,7 +440,7 @@ template <int ACCEL, bool COUNT>
 #define RT_MIN_WAVES 8      /* 64 VGPRs: 8 waves per SIMD; +6 % at steady state over 7 (measured) */
 #endif
 #ifndef RT_MIN_WAVES_LBVH
-#define RT_MIN_WAVES_LBVH 6
+#define RT_MIN_WAVES_LBVH 7    /* measured: 7 beats 6 by 3 %, 8 and 5 lose */
 #endif
 __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : RT_MIN_WAVES) render_kernel(DevScene sc, FrameParams fp, int tiles_per_wave) {
 #ifdef RT_PROFILE
