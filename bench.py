@@ -52,7 +52,7 @@ def parse():
                     choices=["room800", "stock800", "mirrors4k", "spheres800", "spheres4k", "sweep8k"])
     ap.add_argument("--mode", default="strict", choices=["strict", "fast"])
     ap.add_argument("--tiles-per-wave", type=int, default=0)
-    ap.add_argument("--frames-per-launch", type=int, default=16,
+    ap.add_argument("--frames-per-launch", type=int, default=32,
                     help="frames of the camera path rendered by one launch (rt_render_frames_device); 1 = one launch per frame")
     ap.add_argument("--size", type=int, nargs=2, default=None, help="override the workload's frame size (experiments)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -189,7 +189,7 @@ def main():
         full = torch.empty(H * W * 3, dtype=torch.float32, device="cuda" if on_gpu else "cpu") if rank == 0 else None
         recv_bufs = [None] * world
     else:
-        fpl = max(1, min(16, args.frames_per_launch))
+        fpl = max(1, min(32, args.frames_per_launch))
         fb = torch.empty(fpl * H * W * 3, dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -205,7 +205,7 @@ def main():
     batch_cache = {}
 
     def launch_frames(frames):
-        """One call = one launch for up to 16 frames of the path (frames stay resident in `fb`).
+        """One call = one launch for up to 32 frames of the path (frames stay resident in `fb`).
         The marshalled pose arrays of a batch are built once (warm-up) and reused."""
         key = tuple(frames)
         if key not in batch_cache:

@@ -70,7 +70,7 @@ struct DevScene {
 // One launch may render several frames of the same scene (a camera path: consecutive iterations
 // of the frame loop, Source.cpp:1126, with known poses): workgroups [f * blocks_per_frame,
 // (f+1) * blocks_per_frame) render frame f into out + f * frame_stride.
-#define RT_MAX_FRAMES 16
+#define RT_MAX_FRAMES 32      /* 2.4 KB of poses in the kernel arguments (4 KB limit) */
 struct FrameParams {
 	float cam[RT_MAX_FRAMES][3];    // camera.position            Source.cpp:545
 	float m[RT_MAX_FRAMES][16];     // trans, column-major        Source.cpp:1145-1147

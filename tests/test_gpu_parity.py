@@ -153,17 +153,17 @@ def test_recommit_after_edit():
 
 def test_frame_batch_equals_single_frames():
     """rt_render_frames_device: several camera poses in one launch give the same bits as one
-    rt_render per pose (20 poses = two launches of up to RT_MAX_FRAMES_PER_LAUNCH)."""
+    rt_render per pose (40 poses = two launches of up to RT_MAX_FRAMES_PER_LAUNCH)."""
     import torch
     desc = scenes.room(120, 88)
-    poses = scenes.camera_sweep(20, desc.cam_pos, desc.cam_rot)
+    poses = scenes.camera_sweep(40, desc.cam_pos, desc.cam_rot)
     cams = np.array([p for p, _ in poses], np.float32)
     trs = np.stack([api.camera_trans(r) for _, r in poses])
     n = desc.width * desc.height * 3
     with api.Scene.from_desc(desc) as sc:
         sc.commit(0, api.ACCEL_BRUTE)
-        singles = [sc.render(cams[i], trs[i], desc.width, desc.height, desc.depth) for i in range(20)]
-        for count, stride in [(1, n), (3, n + 64), (20, n)]:
+        singles = [sc.render(cams[i], trs[i], desc.width, desc.height, desc.depth) for i in range(40)]
+        for count, stride in [(1, n), (3, n + 64), (40, n)]:
             buf = torch.full((count * stride,), -1.0, dtype=torch.float32, device="cuda:0")
             sc.render_frames_device(0, cams[:count], trs[:count], desc.width, desc.height, desc.depth, api.STRICT,
                                     buf.data_ptr(), stride, torch.cuda.current_stream().cuda_stream)
@@ -172,7 +172,7 @@ def test_frame_batch_equals_single_frames():
             for i in range(count):
                 assert np.array_equal(_bits(got[i, :n].reshape(desc.height, desc.width, 3)), _bits(singles[i])), (count, i)
                 assert np.all(got[i, n:] == -1.0)
-    assert not np.array_equal(singles[0], singles[19])
+    assert not np.array_equal(singles[0], singles[39])
 
 
 def test_controller_path_frames_vs_oracle(oracle):
