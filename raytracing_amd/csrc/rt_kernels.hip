@@ -3,20 +3,22 @@
 //
 // Shape of the kernel (MI355X-first, not the reference's call tree):
 //   * one lane == one pixel at a time; a wavefront (64 lanes) walks 8x8 pixel tiles;
-//   * the scene's float4 SoA planes are staged once per workgroup into LDS and every lane of the
-//     wave reads the SAME triangle per loop trip (one broadcast ds_read_b128 per plane);
+//   * brute force: every lane of the wave visits the SAME box or triangle per loop trip, so the
+//     scene's float4 SoA planes are read through the scalar cache (s_load, operands in SGPRs); the
+//     LBVH path walks a 4-wide quantised tree per lane (rt_lbvh_trav.inl);
 //   * the reference's recursion-by-call (primary castRay -> mirror loop castRays -> per-light
 //     shadow castRays) is flattened into a per-lane state machine with ONE closest-hit loop in the
 //     instruction stream: a lane holds "the ray it is waiting on" (primary, bounce or shadow) and
 //     all 64 lanes sit in that one loop together whatever their stage is;
 //   * lanes whose pixel is finished are refilled with fresh pixels from the wave's tile run using
 //     ballot + mbcnt prefix ranks ("ray regeneration"), so bounce-depth divergence (config 3:
-//     0..16 loop trips per pixel) compacts itself instead of idling lanes.
+//     0..16 loop trips per pixel) compacts itself instead of idling lanes;
+//   * one launch renders up to RT_MAX_FRAMES frames (camera poses) of the same scene.
 //
-// Numerics: this TU is compiled with -ffp-contract=off.  STRICT kernels use only unfused binary32
-// + - * / sqrt in the reference's order (and binary64 at the two places the reference does) and
-// therefore reproduce the CPU frames bit for bit.  FAST kernels (explicit fmaf / rcp, regrouped
-// edge tests) are in rt_fast.inl.
+// Numerics: this TU is compiled with -ffp-contract=off and uses only unfused binary32 + - * / sqrt
+// in the reference's order (and binary64 at the two places the reference does): frames reproduce
+// the reference's CPU frames bit for bit.  Everything that skips work (boxes, limits, the
+// division-free prefilter) only ever skips; no filter decides a hit.
 #include "rt_internal.h"
 
 #include <cstdlib>
@@ -62,8 +64,8 @@ struct LaneCounters {
 __device__ __forceinline__ vec3 xyz(float4 v) { return make3(v.x, v.y, v.z); }
 
 // ---- castRay, brute force (Source.cpp:301-402) ---------------------------------------------
-// `tri` is either the LDS copy or the global planes; the loop index is wave-uniform, so every
-// lane addresses the same float4 (LDS broadcast / scalar load).  `live` masks lanes that hold no
+// `tri` is the global planes; the loop index is wave-uniform, so every lane addresses the same
+// float4.  `live` masks lanes that hold no
 // ray.  Wave-level early outs replace the reference's per-ray `continue`s: the edge terms are
 // only evaluated when some lane of the wave still needs them, lane results are unaffected.
 template <bool COUNT, typename TriPtr>
