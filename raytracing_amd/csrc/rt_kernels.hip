@@ -32,6 +32,12 @@ namespace rt {
 #define RT_PREFILTER_REL 9.5367431640625e-07f      /* 2^-20 */
 static_assert((double)RT_EPS_BELOW <= 0.00001, "EPS_BELOW must not exceed the double literal");
 
+// pixel tile of one wavefront pass: RT_TILE_W x RT_TILE_H = 64 lanes
+#ifndef RT_TILE_W
+#define RT_TILE_W 8
+#endif
+#define RT_TILE_H (64 / RT_TILE_W)
+
 enum { ST_IDLE = 0, ST_PRIMARY = 1, ST_BOUNCE = 2, ST_SHADOW = 3 };
 enum { CTR_PRIMARY = 0, CTR_BOUNCE, CTR_SHADOW, CTR_PLANE, CTR_POINT, CTR_EDGE, CTR_BOX, CTR_PXHIT, CTR_PXMIRROR, CTR_PXLIT, CTR_N };
 
@@ -316,8 +322,8 @@ __device__ __forceinline__ PixelId pixel_of(unsigned int g, unsigned int base_ti
 	const int in = (int)(g & 63u);
 	int tx = tx0 + (int)((g >> 6) - base_tile), ty = ty0;
 	while (tx >= tiles_x) { tx -= tiles_x; ty++; }
-	p.x = tx * 8 + (in & 7);
-	p.ly = ty * 8 + (in >> 3);
+	p.x = tx * RT_TILE_W + (in & (RT_TILE_W - 1));
+	p.ly = ty * RT_TILE_H + (in / RT_TILE_W);
 	p.inside = (p.x < width) && (p.ly < local_rows);
 	return p;
 }
@@ -462,8 +468,8 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : RT_MIN_W
 		__syncthreads();
 	}
 
-	const int tiles_x = (fp.width + 7) >> 3;
-	const int tiles_y = (fp.local_rows + 7) >> 3;
+	const int tiles_x = (fp.width + RT_TILE_W - 1) / RT_TILE_W;
+	const int tiles_y = (fp.local_rows + RT_TILE_H - 1) / RT_TILE_H;
 	// work items fit 32 bits: width * height * 3 < 2^31 is checked on the host (Source.cpp:550 uses int)
 	const unsigned int n_items = (unsigned int)tiles_x * (unsigned int)tiles_y * 64u;
 	const unsigned int wave = __builtin_amdgcn_readfirstlane(block_in_frame * (blockDim.x >> 6) + (threadIdx.x >> 6));
@@ -721,7 +727,7 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 	FrameParams fp = fp_in;
 	if (fp.width <= 0 || fp.local_rows <= 0) return RT_OK;
 	const int n_frames = fp.n_frames < 1 ? 1 : fp.n_frames;
-	const long long tiles = (long long)((fp.width + 7) / 8) * ((fp.local_rows + 7) / 8);
+	const long long tiles = (long long)((fp.width + RT_TILE_W - 1) / RT_TILE_W) * ((fp.local_rows + RT_TILE_H - 1) / RT_TILE_H);
 	if (tiles * 64 > 0xf0000000LL) { set_error("rt_render: %dx%d needs more than 2^32 work items", fp.width, fp.local_rows); return RT_ERR_LIMIT; }
 	int tpw = fp.tiles_per_wave > 0 ? fp.tiles_per_wave : pick_tiles_per_wave(accel, tiles * n_frames);
 	const long long waves = (tiles + tpw - 1) / tpw;
