@@ -220,32 +220,31 @@ __device__ __forceinline__ Hit cast_ray_pruned(const DevScene& sc, c4ptr tri, in
 	const c4ptr cbox = tri.offset_floats(sc.oct_clusters + (long long)oct * sc.oct_cluster_pitch * 8);
 	const c4ptr gbox = tri.offset_floats(sc.oct_groups + (long long)oct * sc.oct_group_pitch * 8);
 	for (int c = 0; c < n_clusters; c++) {
+		// one record per cluster: its box and its run of groups.  A cluster of one group has that
+		// group's box, so its test stands for the group's and the group record is never fetched.
 		int g0, g1;
+		RT_PROF(wp, WP_GROUP);
 		if constexpr (OCT) {
 			const float4 ca = cbox[2 * c], cb = cbox[2 * c + 1];
 			g0 = __float_as_int(cb.z);
 			g1 = g0 + __float_as_int(cb.w);
-			if (g1 - g0 > 1) {
-				RT_PROF(wp, WP_GROUP);
-				if (__builtin_amdgcn_ballot_w64(slab_hit_oct(ca, cb, inv, oi, lim_hi)) == 0) continue;
-			}
+			if (__builtin_amdgcn_ballot_w64(slab_hit_oct(ca, cb, inv, oi, lim_hi)) == 0) continue;
 		} else {
 			const float4 clo = tri[PL_CLO * stride + c];
 			const float4 chi = tri[PL_CHI * stride + c];
 			g0 = __float_as_int(clo.w);
 			g1 = g0 + __float_as_int(chi.w);
-			if (g1 - g0 > 1) {
-				// several groups share this box: one test may skip them all
-				RT_PROF(wp, WP_GROUP);
-				if (__builtin_amdgcn_ballot_w64(slab_hit(clo, chi, inv, oi, lim_hi)) == 0) continue;
-			}
+			if (__builtin_amdgcn_ballot_w64(slab_hit(clo, chi, inv, oi, lim_hi)) == 0) continue;
 		}
+		const bool single = g1 - g0 == 1;
 		for (int g = g0; g < g1; g++) {
-			RT_PROF(wp, WP_GROUP);
-			if constexpr (OCT) {
-				if (__builtin_amdgcn_ballot_w64(slab_hit_oct(gbox[2 * g], gbox[2 * g + 1], inv, oi, lim_hi)) == 0) continue;
-			} else {
-				if (__builtin_amdgcn_ballot_w64(slab_hit(tri[PL_GLO * stride + g], tri[PL_GHI * stride + g], inv, oi, lim_hi)) == 0) continue;
+			if (!single) {
+				RT_PROF(wp, WP_GROUP);
+				if constexpr (OCT) {
+					if (__builtin_amdgcn_ballot_w64(slab_hit_oct(gbox[2 * g], gbox[2 * g + 1], inv, oi, lim_hi)) == 0) continue;
+				} else {
+					if (__builtin_amdgcn_ballot_w64(slab_hit(tri[PL_GLO * stride + g], tri[PL_GHI * stride + g], inv, oi, lim_hi)) == 0) continue;
+				}
 			}
 			RT_PROF(wp, WP_INBOX);
 #pragma unroll
