@@ -186,8 +186,9 @@ def main():
         tile_rows = 16
         rows = api.shard_rows(H, tile_rows, rank, world)
         fb = torch.empty(rows * W * 3, dtype=torch.float32, device="cuda")
-        full = torch.empty(H * W * 3, dtype=torch.float32, device="cuda" if on_gpu else "cpu") if rank == 0 else None
-        recv_bufs = [None] * world
+        # two shard buffers per rank: frame f+1 renders while frame f is on its way to rank 0
+        exchange = sharding.TileExchange(dist, rank, world, H, W, tile_rows,
+                                         lambda n: torch.empty(n, dtype=torch.float32, device="cuda" if on_gpu else "cpu"), depth=2)
     else:
         fpl = max(1, min(32, args.frames_per_launch))
         fb = torch.empty(fpl * H * W * 3, dtype=torch.float32, device="cuda")
@@ -220,17 +221,19 @@ def main():
     def run_steps(frames):
         """`len(frames)` steps (one step = one frame)."""
         if tile_mode:
-            for f in frames:
-                step(f)
+            # row tiles: render this rank's interleaved tiles, then the one exchange step (RCCL), pipelined
+            for i, f in enumerate(frames):
+                buf = exchange.shard(i)
+                if on_gpu:
+                    scene.render_tiles_device(dev, poses[f][0], trans[f], W, H, D, mode, tile_rows, rank, world, buf.data_ptr(), stream)
+                else:   # gloo rehearsal: the shard is staged through host memory; RCCL sends it GPU to GPU
+                    scene.render_tiles_device(dev, poses[f][0], trans[f], W, H, D, mode, tile_rows, rank, world, fb.data_ptr(), stream)
+                    buf.copy_(fb)
+                exchange.submit(i)
+            exchange.drain()
         else:
             for i in range(0, len(frames), fpl):
                 launch_frames(frames[i:i + fpl])
-
-    def step(f):
-        # row tiles: render this rank's interleaved tiles, then the one exchange step (RCCL)
-        scene.render_tiles_device(dev, poses[f][0], trans[f], W, H, D, mode, tile_rows, rank, world, fb.data_ptr(), stream)
-        # (gloo rehearsal: the shard is staged through host memory; RCCL sends it GPU to GPU)
-        sharding.gather_frame(dist, fb if on_gpu else fb.cpu(), full, rank, world, H, W, tile_rows, recv_bufs)
 
     run_steps([my_frames[s % len(my_frames)] for s in range(args.warmup)])
     if not tile_mode:                       # marshal every batch of the timed loop ahead of it

@@ -77,3 +77,70 @@ def gather_frame(dist, shard, full, rank: int, world: int, height: int, width: i
     for k in range(1, world):
         scatter_shard_into_frame(full, bufs[k], height, width, tile_rows, k, world)
     return full
+
+
+class TileExchange:
+    """Pipelined form of :func:`gather_frame` for a sequence of frames: `depth` shard buffers per
+    rank, so that frame f+1 is rendered while frame f is still on its way to rank 0.
+
+    Per frame, every rank calls::
+
+        buf = ex.shard(f)          # compact buffer to render this rank's tiles of frame f into
+        ... rt_render_tiles_device(..., buf) ...
+        done = ex.submit(f)        # start the exchange of frame f
+
+    `submit` on rank 0 returns the list of (frame index, full frame) that became complete with this
+    call (frames complete in order, one call late at most `depth - 1` frames); other ranks get [].
+    `drain()` completes what is still in flight.  `depth == 1` is the serial gather.
+    """
+
+    def __init__(self, dist, rank: int, world: int, height: int, width: int, tile_rows: int, alloc, depth: int = 2):
+        """`alloc(n_floats)` returns a float32 tensor on the device the exchange runs on."""
+        self.dist, self.rank, self.world = dist, rank, world
+        self.h, self.w, self.tile_rows, self.depth = height, width, tile_rows, max(1, depth)
+        n = shard_rows(height, tile_rows, rank, world) * width * 3
+        self._shards = [alloc(n) for _ in range(self.depth)]
+        self._sends = [None] * self.depth                    # rank != 0: the send using shard buffer k
+        if rank == 0:
+            self._full = [alloc(height * width * 3) for _ in range(self.depth)]
+            self._recv = [[alloc(shard_rows(height, tile_rows, k, world) * width * 3) if k else None
+                           for k in range(world)] for _ in range(self.depth)]
+            self._pending = []                               # [(frame, slot, [requests])] in frame order
+
+    def shard(self, f: int):
+        k = f % self.depth
+        if self._sends[k] is not None:                       # the buffer is free once its last send is done
+            self._sends[k].wait()
+            self._sends[k] = None
+        return self._shards[k]                              # (rank 0: slot k's frame was completed by an earlier submit)
+
+    def submit(self, f: int):
+        k = f % self.depth
+        if self.world == 1:
+            scatter_shard_into_frame(self._full[k], self._shards[k], self.h, self.w, self.tile_rows, 0, 1)
+            return [(f, self._full[k])]
+        if self.rank != 0:
+            self._sends[k] = self.dist.isend(self._shards[k], dst=0)
+            return []
+        reqs = [self.dist.irecv(self._recv[k][src], src=src) for src in range(1, self.world)]
+        scatter_shard_into_frame(self._full[k], self._shards[k], self.h, self.w, self.tile_rows, 0, self.world)
+        self._pending.append((f, k, reqs))
+        return self._complete(keep=self.depth - 1)
+
+    def _complete(self, keep: int):
+        done = []
+        while self.rank == 0 and len(self._pending) > keep:
+            f, k, reqs = self._pending.pop(0)
+            for q in reqs:
+                q.wait()
+            for src in range(1, self.world):
+                scatter_shard_into_frame(self._full[k], self._recv[k][src], self.h, self.w, self.tile_rows, src, self.world)
+            done.append((f, self._full[k]))
+        return done
+
+    def drain(self):
+        for k in range(self.depth):
+            if self._sends[k] is not None:
+                self._sends[k].wait()
+                self._sends[k] = None
+        return self._complete(keep=0) if self.rank == 0 else []
