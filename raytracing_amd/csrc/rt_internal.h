@@ -37,7 +37,7 @@ enum { PL_N = 0, PL_P1, PL_P2, PL_P3, PL_E0, PL_E1, PL_E2, PL_GLO, PL_GHI, PL_CL
 // Up to this many triangles the brute-force kernel keeps a per-workgroup LDS table of the primary
 // rays' numerators (rt_kernels.hip, ACCEL 0); forced brute force on larger scenes runs without it
 // (ACCEL 1).  The scene itself is read through the scalar cache in both.
-#define RT_LDS_MAX_TRIS 320
+#define RT_LDS_MAX_TRIS 1024
 
 struct DevScene {
 	const float4* planes;   // PL_COUNT * stride float4
