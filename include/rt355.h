@@ -214,6 +214,13 @@ int         rt_device_count(void);
 
 /* Tuning knob (process-wide): 8x8 pixel tiles each wavefront walks; 0 = library default. */
 int         rt_set_tiles_per_wave(int tiles);
+/* Tuning knob (process-wide): how LBVH scenes are traversed.  RT_TRAVERSAL_AUTO lets each launch
+ * choose by the coherence of an 8x8 tile of rays against the scene's triangles;
+ * both give the reference's bits. */
+#define RT_TRAVERSAL_AUTO     0
+#define RT_TRAVERSAL_PER_LANE 1   /* every lane walks the 4-wide tree with its own stack */
+#define RT_TRAVERSAL_PACKET   2   /* one walk of the binary tree per wavefront (falls back per wave when rays diverge) */
+int         rt_set_traversal(int mode);
 const char* rt_last_error(void);
 const char* rt_version(void);
 

@@ -21,6 +21,7 @@ LIB_PATH = os.environ.get("RT355_LIB") or os.path.join(_HERE, "librt355.so")   #
 
 RT_OK = 0
 ACCEL_AUTO, ACCEL_BRUTE, ACCEL_LBVH = 0, 1, 2
+TRAVERSAL_AUTO, TRAVERSAL_PER_LANE, TRAVERSAL_PACKET = 0, 1, 2
 STRICT, FAST = 0, 1
 TRI_FLOATS = 28
 
@@ -35,7 +36,7 @@ SYMBOLS = (
     "rt_scene_build_ms", "rt_scene_get_bvh", "rt_scene_accel", "rt_camera_trans", "rt_camera_init", "rt_camera_rotate",
     "rt_camera_translate", "rt_camera_frame_time", "rt_camera_step", "rt_camera_path", "rt_render", "rt_render_device",
     "rt_render_frames_device", "rt_render_tiles_device", "rt_shard_rows", "rt_render_stats", "rt_render_multi", "rt_cast_rays",
-    "rt_device_count", "rt_set_tiles_per_wave", "rt_last_error", "rt_version",
+    "rt_device_count", "rt_set_tiles_per_wave", "rt_set_traversal", "rt_last_error", "rt_version",
 )
 
 
@@ -141,6 +142,7 @@ def lib():
     L.rt_cast_rays.argtypes = [vp, ci, _fp, _fp]
     L.rt_device_count.argtypes = []
     L.rt_set_tiles_per_wave.argtypes = [ci]
+    L.rt_set_traversal.argtypes = [ci]
     L.rt_last_error.restype = C.c_char_p
     L.rt_last_error.argtypes = []
     L.rt_version.restype = C.c_char_p
@@ -163,6 +165,11 @@ def _f32(a) -> np.ndarray:
 
 def _p(a: np.ndarray):
     return a.ctypes.data_as(_fp)
+
+
+def set_traversal(mode: int) -> None:
+    """How LBVH scenes are traversed (rt_set_traversal): TRAVERSAL_AUTO | _PER_LANE | _PACKET."""
+    _check(lib().rt_set_traversal(int(mode)))
 
 
 def device_count() -> int:

@@ -122,6 +122,9 @@ int ensure_frame(DeviceState& d, size_t bytes) {
 int g_tiles_per_wave_override = 0;
 
 } // namespace
+
+int g_traversal_mode = RT_TRAVERSAL_AUTO;      // rt_set_traversal; read by the launchers in rt_kernels.hip
+
 } // namespace rt
 
 using namespace rt;
@@ -142,6 +145,12 @@ int rt_device_count(void) {
 
 const char* rt_last_error(void) { return g_err; }
 const char* rt_version(void) { return "rt355 0.1 (gfx950)"; }
+
+int rt_set_traversal(int mode) {
+	if (mode < RT_TRAVERSAL_AUTO || mode > RT_TRAVERSAL_PACKET) { set_error("rt_set_traversal: unknown mode %d", mode); return RT_ERR_INVALID; }
+	g_traversal_mode = mode;
+	return RT_OK;
+}
 
 int rt_set_tiles_per_wave(int tiles) {
 	g_tiles_per_wave_override = tiles < 0 ? 0 : tiles;
@@ -189,6 +198,22 @@ int rt_scene_commit(rt_scene* s, int device, int accel_flags) {
 	if (nl > 0) RT_HIP(hipMemcpy(d.lights, s->lights.data(), (size_t)nl * 4 * sizeof(float), hipMemcpyHostToDevice));
 	RT_HIP(hipMalloc(&d.counters, 32 * sizeof(unsigned long long)));
 	d.build_ms = 0.f;
+	{   // scene diagonal over the mean triangle box diagonal (rt_kernels.hip launch_render: packet or per-lane traversal)
+		double sum = 0.0;
+		for (int i = 0; i < n; i++) {
+			const float* v = s->tris.data() + (size_t)i * RT_TRI_FLOATS + 6;      // p1 p2 p3
+			double dd = 0.0;
+			for (int k = 0; k < 3; k++) {
+				const float lo = fminf(v[k], fminf(v[3 + k], v[6 + k])), hi = fmaxf(v[k], fmaxf(v[3 + k], v[6 + k]));
+				dd += (double)(hi - lo) * (double)(hi - lo);
+			}
+			sum += sqrt(dd);
+		}
+		double diag = 0.0;
+		for (int k = 0; k < 3; k++) diag += (double)(d.bb_hi[k] - d.bb_lo[k]) * (double)(d.bb_hi[k] - d.bb_lo[k]);
+		const double mean = n > 0 ? sum / n : 0.0;
+		d.packet_scale = (mean > 0.0 && box_finite) ? (float)(sqrt(diag) / mean) : 3.0e38f;
+	}
 	if (d.accel == RT_ACCEL_LBVH) {
 		int rc = lbvh_build(s, d, nullptr);
 		if (rc != RT_OK) return rc;

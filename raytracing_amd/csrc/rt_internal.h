@@ -51,7 +51,11 @@ struct DevScene {
 	const uint4* bvh4;         // 4-wide quantised collapse of it, 64 B per node: what traversal walks
 	const float4* tri_aos;     // 8 float4 per triangle (N P1 P2 P3 E0 E1 E2 -): one burst per leaf test
 	int bvh_root;
-	int pad2;
+	int skip_count;            // inner nodes per octant of the packet records (0: none)
+	// Wave-uniform ("packet") traversal of the same binary tree (rt_kernels.hip cast_ray_packet):
+	// per octant and inner node one 64-byte record with BOTH children, the one nearer along the
+	// octant first: (nearA.xyz, farA.xyz, refA, refB, nearB.xyz, farB.xyz, -, -).
+	const float4* skiplist;
 	// Octant-ordered copies of the group and cluster boxes (brute force): for each of the 8 sign
 	// combinations of a ray direction, entry e is 8 floats (near.xyz, far.xyz, a, b) where near/far
 	// are the box faces a ray of that octant meets first/last per axis; clusters carry a = first
@@ -61,7 +65,7 @@ struct DevScene {
 	// scene bounding box, padded (host: rt_api.cpp scene_box); +-inf when the scene has none
 	float bb_lo[3], bb_hi[3];
 	float far_guard;        // |origin| beyond this: the box tests are switched off for the ray
-	int pad3;
+	float packet_scale;     // scene diagonal / mean triangle box diagonal (launcher: is an 8x8 tile of rays coherent?)
 };
 
 // Per-launch frame description.  Rows are addressed as LOCAL rows of this shard:
@@ -97,6 +101,9 @@ struct DeviceState {
 	void* bvh_nodes = nullptr;
 	void* bvh4 = nullptr;
 	void* tri_aos = nullptr;
+	void* skiplist = nullptr;
+	int skip_count = 0;
+	float packet_scale = 0.f;
 	void* counters = nullptr;
 	int bvh_root = 0;
 	int stride = 0;
@@ -140,6 +147,7 @@ float scene_box(const std::vector<float>& tris, float lo[3], float hi[3]);   // 
 
 // rt_kernels.hip
 DevScene dev_scene(const rt_scene* s, const DeviceState& d);
+extern int g_traversal_mode;     // rt_set_traversal
 int launch_render(const DevScene& sc, const FrameParams& fp, int accel, int render_flags, bool count, hipStream_t stream);
 int launch_cast_rays(const DevScene& sc, int accel, int n, const float* d_rays7, float* d_out6, hipStream_t stream);
 

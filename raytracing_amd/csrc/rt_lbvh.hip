@@ -34,6 +34,7 @@
 #include "rt_internal.h"
 
 #include <cstring>
+#include <cstdlib>
 #include <rocprim/device/device_radix_sort.hpp>
 
 namespace rt {
@@ -272,6 +273,49 @@ __global__ void __launch_bounds__(256) k_aos(const float4* __restrict__ planes, 
 	o[7] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// 7. k_packet: per octant, the node's two children with the one nearer along that octant first and
+//    the box faces ordered near/far per axis (rt_internal.h DevScene::skiplist): what the
+//    wave-uniform traversal reads with one 64-byte scalar load per node.
+__global__ void __launch_bounds__(256) k_packet(const float4* __restrict__ nodes, int n_nodes, float4* __restrict__ out) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_nodes) return;
+	const float* nd = (const float*)(nodes + (size_t)i * 4);
+	float lo[2][3], hi[2][3];
+	int ref[2];
+	for (int side = 0; side < 2; side++) {
+		for (int k = 0; k < 3; k++) { lo[side][k] = nd[side * 6 + k]; hi[side][k] = nd[side * 6 + 3 + k]; }
+		ref[side] = __float_as_int(nd[12 + side]);
+	}
+	// the axis on which the two centres are farthest apart decides which child is nearer
+	int axis = 0;
+	float best = -1.f;
+	for (int k = 0; k < 3; k++) {
+		const float sep = fabsf((lo[0][k] + hi[0][k]) - (lo[1][k] + hi[1][k]));
+		if (sep > best) { best = sep; axis = k; }
+	}
+	const bool left_lower = (lo[0][axis] + hi[0][axis]) <= (lo[1][axis] + hi[1][axis]);
+	for (int oct = 0; oct < 8; oct++) {
+		const bool neg_axis = (oct >> axis) & 1;
+		const int a = (left_lower != neg_axis) ? 0 : 1, b = 1 - a;
+		float v[16];
+		for (int k = 0; k < 3; k++) {
+			const bool neg = (oct >> k) & 1;
+			v[k] = neg ? hi[a][k] : lo[a][k];
+			v[3 + k] = neg ? lo[a][k] : hi[a][k];
+			v[8 + k] = neg ? hi[b][k] : lo[b][k];
+			v[11 + k] = neg ? lo[b][k] : hi[b][k];
+		}
+		v[6] = __int_as_float(ref[a]);
+		v[7] = __int_as_float(ref[b]);
+		v[14] = 0.f; v[15] = 0.f;
+		float4* o = out + ((size_t)oct * n_nodes + i) * 4;
+		o[0] = make_float4(v[0], v[1], v[2], v[3]);
+		o[1] = make_float4(v[4], v[5], v[6], v[7]);
+		o[2] = make_float4(v[8], v[9], v[10], v[11]);
+		o[3] = make_float4(v[12], v[13], v[14], v[15]);
+	}
+}
+
 template <typename T>
 int dev_alloc(T** p, size_t count) {
 	hipError_t e = hipMalloc((void**)p, count * sizeof(T));
@@ -285,9 +329,12 @@ void lbvh_free(DeviceState& d) {
 	if (d.bvh_nodes) (void)hipFree(d.bvh_nodes);
 	if (d.bvh4) (void)hipFree(d.bvh4);
 	if (d.tri_aos) (void)hipFree(d.tri_aos);
+	if (d.skiplist) (void)hipFree(d.skiplist);
 	d.bvh_nodes = nullptr;
 	d.bvh4 = nullptr;
 	d.tri_aos = nullptr;
+	d.skiplist = nullptr;
+	d.skip_count = 0;
 }
 
 int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
@@ -303,7 +350,7 @@ int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 	int *parent_int = nullptr, *parent_leaf = nullptr;
 	unsigned int* flags = nullptr;
 	void* temp = nullptr;
-	float4 *nodes = nullptr, *aos = nullptr;
+	float4 *nodes = nullptr, *aos = nullptr, *pkt = nullptr;
 	uint4* nodes4 = nullptr;
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	int rc = RT_OK;
@@ -317,8 +364,8 @@ int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 		if (e0) (void)hipEventDestroy(e0);
 		if (e1) (void)hipEventDestroy(e1);
 	};
-#define LB_TRY(x) do { rc = (x); if (rc != RT_OK) { cleanup(); if (nodes) (void)hipFree(nodes); if (nodes4) (void)hipFree(nodes4); if (aos) (void)hipFree(aos); return rc; } } while (0)
-#define LB_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = hip_fail(e_, #x); cleanup(); if (nodes) (void)hipFree(nodes); if (nodes4) (void)hipFree(nodes4); if (aos) (void)hipFree(aos); return rc; } } while (0)
+#define LB_TRY(x) do { rc = (x); if (rc != RT_OK) { cleanup(); if (nodes) (void)hipFree(nodes); if (nodes4) (void)hipFree(nodes4); if (aos) (void)hipFree(aos); if (pkt) (void)hipFree(pkt); return rc; } } while (0)
+#define LB_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = hip_fail(e_, #x); cleanup(); if (nodes) (void)hipFree(nodes); if (nodes4) (void)hipFree(nodes4); if (aos) (void)hipFree(aos); if (pkt) (void)hipFree(pkt); return rc; } } while (0)
 	LB_TRY(dev_alloc(&keys, (size_t)n));
 	LB_TRY(dev_alloc(&keys_sorted, (size_t)n));
 	LB_TRY(dev_alloc(&parent_int, (size_t)n));
@@ -327,6 +374,8 @@ int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 	LB_TRY(dev_alloc(&nodes, (size_t)(n - 1) * 4));
 	LB_TRY(dev_alloc(&nodes4, (size_t)(n - 1) * 4));
 	LB_TRY(dev_alloc(&aos, (size_t)n * 8));
+	const bool want_packet = true;
+	LB_TRY(dev_alloc(&pkt, (size_t)(n - 1) * 4 * 8));
 	size_t temp_bytes = 0;
 	int index_bits = 1;
 	while (index_bits < 31 && (1ll << index_bits) < (long long)n) index_bits++;
@@ -358,6 +407,10 @@ int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 	LB_HIP(hipGetLastError());
 	hipLaunchKernelGGL(k_aos, dim3(blocks_n), dim3(256), 0, stream, planes, d.stride, n, aos);
 	LB_HIP(hipGetLastError());
+	if (want_packet) {
+		hipLaunchKernelGGL(k_packet, dim3(blocks_n), dim3(256), 0, stream, (const float4*)nodes, n - 1, pkt);
+		LB_HIP(hipGetLastError());
+	}
 	LB_HIP(hipEventRecord(e1, stream));
 	LB_HIP(hipEventSynchronize(e1));
 	float ms = 0.f;
@@ -371,6 +424,7 @@ int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 		(void)hipFree(nodes);
 		(void)hipFree(nodes4);
 		(void)hipFree(aos);
+		if (pkt) (void)hipFree(pkt);
 		return RT_ERR_DEVICE;
 	}
 #undef LB_TRY
@@ -379,6 +433,8 @@ int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 	d.bvh_nodes = nodes;
 	d.bvh4 = nodes4;
 	d.tri_aos = aos;
+	d.skiplist = pkt;
+	d.skip_count = pkt ? n - 1 : 0;
 	d.bvh_root = 0;
 	d.build_ms = ms;
 	return RT_OK;
