@@ -483,30 +483,36 @@ __device__ __forceinline__ Hit trace(const DevScene& sc, const float4* lds_tri, 
                                      vec3 o, vec3 d, int skip, bool live, bool shadow, float dist, bool all_primary,
                                      LaneCounters& lc, WaveProf& wp) {
 	if constexpr (ACCEL == 2) {
-		if (!COUNT && sc.skip_count > 0) {
-			// wave-uniform walk when every live ray shares an octant and may trust the boxes
-			const vec3 ds = make3(fabsf(d.x) < 1e-30f ? 1e-30f : d.x, fabsf(d.y) < 1e-30f ? 1e-30f : d.y, fabsf(d.z) < 1e-30f ? 1e-30f : d.z);
-			const bool near = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) < sc.far_guard;
-			const unsigned int lane_oct = (__float_as_uint(ds.x) >> 31) | ((__float_as_uint(ds.y) >> 31) << 1) | ((__float_as_uint(ds.z) >> 31) << 2);
-			const unsigned long long lv = __builtin_amdgcn_ballot_w64(live);
-			const int oct = (int)__builtin_amdgcn_readlane(lane_oct, lv ? __builtin_ctzll(lv) : 0);
-			if (__builtin_amdgcn_ballot_w64(live && (lane_oct != (unsigned int)oct || !near)) == 0ull) {
-				const vec3 inv = make3(__builtin_amdgcn_rcpf(ds.x), __builtin_amdgcn_rcpf(ds.y), __builtin_amdgcn_rcpf(ds.z));
-				const vec3 oi = make3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
-				const float ex = fminf(fminf(fmaxf(__builtin_fmaf(sc.bb_lo[0], inv.x, oi.x), __builtin_fmaf(sc.bb_hi[0], inv.x, oi.x)),
-				                             fmaxf(__builtin_fmaf(sc.bb_lo[1], inv.y, oi.y), __builtin_fmaf(sc.bb_hi[1], inv.y, oi.y))),
-				                       fmaxf(__builtin_fmaf(sc.bb_lo[2], inv.z, oi.z), __builtin_fmaf(sc.bb_hi[2], inv.z, oi.z)));
-				float lim = fminf(ex + fabsf(ex) * 1e-4f, 1e9f);
-				if (shadow) lim = fminf(lim, __uint_as_float(__float_as_uint(dist) + 1u));
-				lim = fminf(lim, 1e9f);
-				if (!live) lim = -1.0f;
-				RT_PROF(wp, WP_TRACE);
-				return cast_ray_packet(sc, oct, o, d, inv, oi, skip, lim, shadow, wp);
-			}
-		}
-		RT_PROF(wp, WP_INBOX);
 		return cast_ray_lbvh<COUNT>(sc, (int*)lds_tri, o, d, skip, live, shadow, dist, lc, wp);
-	} else if constexpr (COUNT) {
+	} else if constexpr (ACCEL == 3) {
+		// packets: one walk of the tree per octant present in the wave (one pass for almost every wave)
+		const vec3 ds = make3(fabsf(d.x) < 1e-30f ? 1e-30f : d.x, fabsf(d.y) < 1e-30f ? 1e-30f : d.y, fabsf(d.z) < 1e-30f ? 1e-30f : d.z);
+		const bool near = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) < sc.far_guard;   // false for NaN too
+		vec3 inv = make3(__builtin_amdgcn_rcpf(ds.x), __builtin_amdgcn_rcpf(ds.y), __builtin_amdgcn_rcpf(ds.z));
+		vec3 oi = make3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
+		const float ex = fminf(fminf(fmaxf(__builtin_fmaf(sc.bb_lo[0], inv.x, oi.x), __builtin_fmaf(sc.bb_hi[0], inv.x, oi.x)),
+		                             fmaxf(__builtin_fmaf(sc.bb_lo[1], inv.y, oi.y), __builtin_fmaf(sc.bb_hi[1], inv.y, oi.y))),
+		                       fmaxf(__builtin_fmaf(sc.bb_lo[2], inv.z, oi.z), __builtin_fmaf(sc.bb_hi[2], inv.z, oi.z)));
+		float lim = near ? fminf(ex + fabsf(ex) * 1e-4f, 1e9f) : 1e9f;
+		if (shadow) lim = fminf(lim, __uint_as_float(__float_as_uint(dist) + 1u));
+		lim = fminf(lim, 1e9f);
+		if (!near) { inv = make3(0.f, 0.f, 0.f); oi = make3(0.f, 0.f, 0.f); }   // boxes not trusted: every box tests as hit for this lane
+		const unsigned int lane_oct = (__float_as_uint(ds.x) >> 31) | ((__float_as_uint(ds.y) >> 31) << 1) | ((__float_as_uint(ds.z) >> 31) << 2);
+		unsigned long long todo = __builtin_amdgcn_ballot_w64(live);
+		Hit h;
+		h.t = 1e9f;
+		h.idx = -1;
+		h.p = make3(0.f, 0.f, 0.f);
+		while (todo) {
+			const unsigned int oct = __builtin_amdgcn_readlane(lane_oct, __builtin_ctzll(todo));
+			const bool mine = live && lane_oct == oct;
+			todo &= ~__builtin_amdgcn_ballot_w64(mine);
+			RT_PROF(wp, WP_TRACE);
+			const Hit hp = cast_ray_packet(sc, (int)oct, o, d, inv, oi, skip, mine ? lim : -1.0f, shadow, wp);
+			if (mine) h = hp;
+		}
+		return h;
+		} else if constexpr (COUNT) {
 		// instrumented, reference-order loop: the counters follow Source.cpp's own short-circuits
 		return cast_ray_brute<true>(sc.planes, sc.stride, sc.n_tris, o, d, skip, live, lc);
 	} else {
@@ -558,10 +564,13 @@ template <int ACCEL, bool COUNT>
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 8      /* 64 VGPRs: 8 waves per SIMD; +6 % at steady state over 7 (measured) */
 #endif
+#ifndef RT_MIN_WAVES_PACKET
+#define RT_MIN_WAVES_PACKET 8
+#endif
 #ifndef RT_MIN_WAVES_LBVH
 #define RT_MIN_WAVES_LBVH 7    /* measured: 7 beats 6 by 3 %, 8 and 5 lose */
 #endif
-__global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : RT_MIN_WAVES) render_kernel(DevScene sc, FrameParams fp, int tiles_per_wave) {
+__global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL == 3 ? RT_MIN_WAVES_PACKET : RT_MIN_WAVES)) render_kernel(DevScene sc, FrameParams fp, int tiles_per_wave) {
 #ifdef RT_PROFILE
 	const unsigned long long t_start = __builtin_amdgcn_s_memtime();
 #endif
@@ -869,6 +878,7 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 	if (accel == RT_ACCEL_LBVH) {
 		const size_t lds = (size_t)RT_STACK_LDS * RT_STACK_PITCH * sizeof(int);   // [entry][lane]
 		if (count) hipLaunchKernelGGL((render_kernel<2, true>), grid, block, lds, stream, sc_sel, fp, tpw);
+		else if (sc_sel.skip_count > 0) hipLaunchKernelGGL((render_kernel<3, false>), grid, block, 0, stream, sc_sel, fp, tpw);
 		else hipLaunchKernelGGL((render_kernel<2, false>), grid, block, lds, stream, sc_sel, fp, tpw);
 	} else if (sc.n_tris <= RT_LDS_MAX_TRIS) {
 		const size_t lds = (size_t)lds_stride_of(sc.n_tris) * sizeof(float);
@@ -889,7 +899,8 @@ int launch_cast_rays(const DevScene& sc, int accel, int n, const float* d_rays7,
 	if (accel == RT_ACCEL_LBVH) {
 		DevScene sc_sel = sc;
 		if (g_traversal_mode != RT_TRAVERSAL_PACKET) sc_sel.skip_count = 0;      // ray batches are per lane unless packets are forced
-		hipLaunchKernelGGL((cast_rays_kernel<2>), grid, block, (size_t)RT_STACK_LDS * 256 * sizeof(int), stream, sc_sel, n, d_rays7, d_out6);
+		if (sc_sel.skip_count > 0) hipLaunchKernelGGL((cast_rays_kernel<3>), grid, block, 0, stream, sc_sel, n, d_rays7, d_out6);
+		else hipLaunchKernelGGL((cast_rays_kernel<2>), grid, block, (size_t)RT_STACK_LDS * 256 * sizeof(int), stream, sc_sel, n, d_rays7, d_out6);
 	} else if (sc.n_tris <= RT_LDS_MAX_TRIS) {
 		const size_t lds = (size_t)lds_stride_of(sc.n_tris) * sizeof(float);
 		hipLaunchKernelGGL((cast_rays_kernel<0>), grid, block, lds, stream, sc, n, d_rays7, d_out6);
