@@ -38,7 +38,7 @@ extern "C" {
 #define RT_ACCEL_AUTO    0   /* brute force up to RT_BRUTE_AUTO_MAX triangles, LBVH above */
 #define RT_ACCEL_BRUTE   1   /* the reference's O(N) loop over every triangle (Src:301)   */
 #define RT_ACCEL_LBVH    2   /* GPU-built Morton/Karras LBVH                              */
-#define RT_BRUTE_AUTO_MAX 1024  /* measured crossover at 800x800: brute force 37 us vs LBVH 41 us at 972 triangles, 50 vs 49 at 1612 */
+#define RT_BRUTE_AUTO_MAX 128   /* measured at 800x800 with packet traversal: 172 triangles 18.7 us brute vs 18.3 us LBVH, 972: 37 vs 26; room (26): 20 vs 25 */
 
 /* rt_render* flags */
 #define RT_RENDER_STRICT 0   /* unfused IEEE binary32 in the reference's operation order:
