@@ -299,14 +299,10 @@ __device__ __forceinline__ void packet_leaf(const DevScene& sc, int i, vec3 o, v
 	const vec3 nn = xyz(N4), p1 = xyz(P14);
 	const float num = dot(p1 - o, nn);
 	const float den = dot(d, nn);
-	const float qa = lim_hi * den, qb = eps_lo * den;
-	const bool normal = __builtin_amdgcn_classf(qb, 0x108);
-	const bool maybe = !normal || (__builtin_amdgcn_fmed3f(num, qa, qb) == num);
-	if (__builtin_amdgcn_ballot_w64(maybe) == 0) return;
-	RT_PROF(wp, WP_MAYBE);
+	// (no division-free prefilter here: nine of ten triangles whose box a packet reaches are candidates)
 	const float t = num / den;                                              // Source.cpp:383
 	const bool better = (t < lim) || (t == h.t && i < h.idx);               // Source.cpp:391 + index order
-	const bool cand = maybe && (t > RT_EPS_BELOW) && better;
+	const bool cand = (t > RT_EPS_BELOW) && better;
 	if (__builtin_amdgcn_ballot_w64(cand) == 0) return;
 	RT_PROF(wp, WP_CAND);
 	const float4 P24 = T[2], P34 = T[3], E0 = T[4], E1 = T[5], E2 = T[6];   // the rest of the record in one go
@@ -343,12 +339,13 @@ __device__ __forceinline__ Hit cast_ray_packet(const DevScene& sc, int oct, vec3
 		const int refA = __float_as_int(q1.z), refB = __float_as_int(q1.w);
 		RT_PROF(wp, WP_GROUP);
 		const bool hitA = __builtin_amdgcn_ballot_w64(slab_hit_oct(q0, q1, inv, oi, lim_hi)) != 0;
-		const bool hitB = __builtin_amdgcn_ballot_w64(slab_hit_oct(q2, q3, inv, oi, lim_hi)) != 0;
 		int next = -1;
 		if (hitA) {
 			if (refA < 0) packet_leaf(sc, ~refA, o, d, skip, first_only, eps_lo, h, lim, lim_hi, wp);
 			else next = refA;
 		}
+		// the farther child is tested after a near LEAF has had its chance to shorten the limits
+		const bool hitB = __builtin_amdgcn_ballot_w64(slab_hit_oct(q2, q3, inv, oi, lim_hi)) != 0;
 		if (hitB) {
 			if (refB < 0) packet_leaf(sc, ~refB, o, d, skip, first_only, eps_lo, h, lim, lim_hi, wp);
 			else if (next >= 0) {
