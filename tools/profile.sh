@@ -43,7 +43,7 @@ import csv, sys, json, collections, os
 out, tag = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(list)
 for r in csv.DictReader(open(os.path.join(out, "pmc_lbvh", "p_counter_collection.csv"))):
-    if "render_kernel<2, false>" in r["Kernel_Name"]:
+    if "render_kernel<2, false>" in r["Kernel_Name"] or "render_kernel<3, false>" in r["Kernel_Name"]:   # per-lane or packet traversal
         acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 summ = {k: sum(v) / len(v) for k, v in acc.items()}
 w = summ.get("SQ_WAVES", 1.0)
