@@ -85,3 +85,39 @@ def test_coherent_ray_batches_through_packets():
         b = sc.cast_rays(rays)
     assert np.array_equal(_bits(a), _bits(b))
     assert a[:, 0].mean() > 0.9
+
+
+def test_far_origin_and_odd_rays_through_packets(oracle):
+    """Packets with rays whose boxes are not trusted (origins up to 10^7 scene scales away: every box
+    tests as hit for such a lane), zero and tiny directions, and NaN components: same answers as the
+    oracle's castRay."""
+    desc = _soup(11, 120, 10.0)
+    tris, _ = oracle.build_scene(desc)
+    rng = np.random.default_rng(3)
+    rays = []
+    for k in range(640):
+        target = rng.uniform(-10, 10, 3)
+        direction = rng.normal(size=3)
+        direction /= np.linalg.norm(direction)
+        dist = 10.0 ** rng.uniform(1, 7.5)
+        o = target - direction * dist
+        rays.append([*o, *(direction * (1.0 if k % 2 else dist)), -1.0])
+    rays = np.array(rays, np.float32)
+    rays[5, 3:6] = 0.0                      # zero direction
+    rays[70, 3:6] = (1e-38, 0.0, 1e-38)     # denormal-ish direction
+    rays[130, 0] = np.nan                   # NaN origin component
+    rays[200, 4] = np.inf                   # infinite direction component
+    want = np.stack([oracle.cast_ray(tris, r[0:3], r[3:6], -1) for r in rays])
+    with api.Scene.from_desc(desc) as sc:
+        sc.commit(0, api.ACCEL_LBVH)
+        got = sc.cast_rays(rays)
+    assert np.array_equal(got[:, 0], want[:, 0])
+    assert np.array_equal(got[:, 1], want[:, 1])
+    hit = want[:, 0] > 0
+    assert np.array_equal(_bits(got[hit]), _bits(want[hit]))
+
+
+def test_tiny_frames_and_many_lights_through_packets(oracle):
+    for w, h in [(1, 1), (3, 2), (8, 8), (9, 17), (65, 7)]:
+        desc = _soup(21, 200, 5.0, w=w, h=h, depth=4, lights=8)
+        assert np.array_equal(_bits(_lbvh_frame(desc)), _bits(oracle.render_desc(desc)))
