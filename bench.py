@@ -288,7 +288,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": label, "accel": accel_name, "mode": args.mode, "width": W, "height": H, "max_bounces": D,
+            "config": {"workload": label, "accel": accel_name, "traversal": {0: None, 1: "per-lane", 2: "packet"}[scene.traversal(dev, trans[0], W, H)], "mode": args.mode, "width": W, "height": H, "max_bounces": D,
                        "triangles": scene.n_triangles, "lights": scene.n_lights,
                        "frames_per_launch": (fpl if not tile_mode else 1),
                        "frames": ("64-pose camera sweep, frame (step*N + rank) mod 64, %d frames per launch" % fpl) if not tile_mode else "64-pose sweep, interleaved 16-row tiles, gather to rank 0",

@@ -221,6 +221,9 @@ int         rt_set_tiles_per_wave(int tiles);
 #define RT_TRAVERSAL_PER_LANE 1   /* every lane walks the 4-wide tree with its own stack */
 #define RT_TRAVERSAL_PACKET   2   /* one walk of the binary tree per wavefront (falls back per wave when rays diverge) */
 int         rt_set_traversal(int mode);
+/* Which traversal a frame of this size and pose would get on `device`: RT_TRAVERSAL_PER_LANE or
+ * RT_TRAVERSAL_PACKET for an LBVH commit, 0 for a brute-force commit. */
+int         rt_scene_traversal(const rt_scene* s, int device, const float trans16[16], int width, int height);
 const char* rt_last_error(void);
 const char* rt_version(void);
 

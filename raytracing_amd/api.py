@@ -36,7 +36,7 @@ SYMBOLS = (
     "rt_scene_build_ms", "rt_scene_get_bvh", "rt_scene_accel", "rt_camera_trans", "rt_camera_init", "rt_camera_rotate",
     "rt_camera_translate", "rt_camera_frame_time", "rt_camera_step", "rt_camera_path", "rt_render", "rt_render_device",
     "rt_render_frames_device", "rt_render_tiles_device", "rt_shard_rows", "rt_render_stats", "rt_render_multi", "rt_cast_rays",
-    "rt_device_count", "rt_set_tiles_per_wave", "rt_set_traversal", "rt_last_error", "rt_version",
+    "rt_device_count", "rt_set_tiles_per_wave", "rt_set_traversal", "rt_scene_traversal", "rt_last_error", "rt_version",
 )
 
 
@@ -143,6 +143,7 @@ def lib():
     L.rt_device_count.argtypes = []
     L.rt_set_tiles_per_wave.argtypes = [ci]
     L.rt_set_traversal.argtypes = [ci]
+    L.rt_scene_traversal.argtypes = [vp, ci, _fp, ci, ci]
     L.rt_last_error.restype = C.c_char_p
     L.rt_last_error.argtypes = []
     L.rt_version.restype = C.c_char_p
@@ -393,6 +394,11 @@ class Scene:
         cam, tr = _f32(cam_pos), _f32(trans16)
         _check(lib().rt_render_device(self._h, device, _p(cam), _p(tr), width, height, max_bounces, mode,
                                       C.c_void_p(d_out_ptr), C.c_void_p(stream)))
+
+    def traversal(self, device: int, trans16, width: int, height: int) -> int:
+        """TRAVERSAL_PACKET / TRAVERSAL_PER_LANE a frame of this size and pose gets (0: brute force)."""
+        tr = _f32(trans16)
+        return _check(lib().rt_scene_traversal(self._h, device, _p(tr), width, height))
 
     def render_frames_device(self, device: int, cam_pos3, trans16, width: int, height: int, max_bounces: int,
                              mode: int, d_out_ptr: int, frame_stride_floats: int = 0, stream: int = 0) -> None:

@@ -146,6 +146,14 @@ int rt_device_count(void) {
 const char* rt_last_error(void) { return g_err; }
 const char* rt_version(void) { return "rt355 0.1 (gfx950)"; }
 
+int rt_scene_traversal(const rt_scene* s, int device, const float trans16[16], int width, int height) {
+	if (!s || !trans16) { set_error("rt_scene_traversal: NULL argument"); return RT_ERR_INVALID; }
+	auto it = s->dev.find(device);
+	if (it == s->dev.end() || !it->second.valid) { set_error("rt_scene_traversal: not committed on device %d", device); return RT_ERR_STATE; }
+	if (it->second.accel != RT_ACCEL_LBVH) return 0;
+	return use_packets(dev_scene(s, it->second), trans16, width, height) ? RT_TRAVERSAL_PACKET : RT_TRAVERSAL_PER_LANE;
+}
+
 int rt_set_traversal(int mode) {
 	if (mode < RT_TRAVERSAL_AUTO || mode > RT_TRAVERSAL_PACKET) { set_error("rt_set_traversal: unknown mode %d", mode); return RT_ERR_INVALID; }
 	g_traversal_mode = mode;

@@ -148,6 +148,7 @@ float scene_box(const std::vector<float>& tris, float lo[3], float hi[3]);   // 
 // rt_kernels.hip
 DevScene dev_scene(const rt_scene* s, const DeviceState& d);
 extern int g_traversal_mode;     // rt_set_traversal
+bool use_packets(const DevScene& sc, const float trans16[16], int width, int height);   // the launcher's choice for an LBVH scene
 int launch_render(const DevScene& sc, const FrameParams& fp, int accel, int render_flags, bool count, hipStream_t stream);
 int launch_cast_rays(const DevScene& sc, int accel, int n, const float* d_rays7, float* d_out6, hipStream_t stream);
 

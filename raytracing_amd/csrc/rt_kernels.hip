@@ -829,6 +829,18 @@ DevScene dev_scene(const rt_scene* s, const DeviceState& d) {
 	return sc;
 }
 
+bool use_packets(const DevScene& sc, const float trans16[16], int width, int height) {
+	if (sc.skip_count <= 0) return false;
+	if (g_traversal_mode != RT_TRAVERSAL_AUTO) return g_traversal_mode == RT_TRAVERSAL_PACKET;
+	static const int env_packet = [] { const char* e = getenv("RT355_PACKET"); return e ? atoi(e) : -1; }();   // experiments
+	if (env_packet >= 0) return env_packet != 0;
+	const float* m = trans16;
+	const float du = sqrtf(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]) / (float)(width > 0 ? width : 1);
+	const float dv = sqrtf(m[4] * m[4] + m[5] * m[5] + m[6] * m[6]) / (float)(height > 0 ? height : 1);
+	const float footprint = 8.0f * 0.5f * (du + dv) * sc.packet_scale;
+	return footprint < 5.0f;
+}
+
 static int pick_tiles_per_wave(int accel, long long tiles) {
 	// 8x8 tiles per wavefront.  Measured: with two tiles a lane that finishes its pixel
 	// early (a miss, a matte hit next to a 16-bounce mirror path) takes the next pixel instead of
@@ -861,16 +873,7 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 	// of the mean triangle size; measured on the 100k-triangle scene: packets win below ~5 (800x800: 4.6, +3 %; 1200: 3.1,
 	// 1.27x; 1600: 2.3, 1.4x; 2400: 1.5, 1.6x; 3840x2160: 1.3, 1.7x) and lose above (400x400: 9.2, 0.6x).
 	DevScene sc_sel = sc;
-	if (accel == RT_ACCEL_LBVH && sc.skip_count > 0) {
-		static const int env_packet = [] { const char* e = getenv("RT355_PACKET"); return e ? atoi(e) : -1; }();   // experiments
-		const float* m = fp.m[0];
-		const float du = sqrtf(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]) / (float)fp.width;
-		const float dv = sqrtf(m[4] * m[4] + m[5] * m[5] + m[6] * m[6]) / (float)(fp.height > 0 ? fp.height : 1);
-		const float footprint = 8.0f * 0.5f * (du + dv) * sc.packet_scale;
-		const bool use_packet = g_traversal_mode != RT_TRAVERSAL_AUTO ? g_traversal_mode == RT_TRAVERSAL_PACKET
-		                        : env_packet >= 0 ? env_packet != 0 : footprint < 5.0f;
-		if (!use_packet) sc_sel.skip_count = 0;
-	}
+	if (accel == RT_ACCEL_LBVH && !use_packets(sc, fp.m[0], fp.width, fp.height)) sc_sel.skip_count = 0;
 	const dim3 grid((unsigned)(blocks * n_frames)), block((unsigned)threads);
 	if (accel == RT_ACCEL_LBVH) {
 		const size_t lds = (size_t)RT_STACK_LDS * RT_STACK_PITCH * sizeof(int);   // [entry][lane]

@@ -121,3 +121,17 @@ def test_tiny_frames_and_many_lights_through_packets(oracle):
     for w, h in [(1, 1), (3, 2), (8, 8), (9, 17), (65, 7)]:
         desc = _soup(21, 200, 5.0, w=w, h=h, depth=4, lights=8)
         assert np.array_equal(_bits(_lbvh_frame(desc)), _bits(oracle.render_desc(desc)))
+
+
+def test_launcher_choice_is_reported():
+    api.set_traversal(api.TRAVERSAL_AUTO)
+    desc = scenes.spheres(20, 4, 8, 8)
+    with api.Scene.from_desc(desc) as sc:
+        sc.commit(0, api.ACCEL_LBVH)
+        tr = api.camera_trans(desc.cam_rot)
+        assert sc.traversal(0, tr, 400, 400) == api.TRAVERSAL_PER_LANE          # footprint 9.2
+        assert sc.traversal(0, tr, 3840, 2160) == api.TRAVERSAL_PACKET           # footprint 1.3
+        api.set_traversal(api.TRAVERSAL_PER_LANE)
+        assert sc.traversal(0, tr, 3840, 2160) == api.TRAVERSAL_PER_LANE
+        sc.commit(0, api.ACCEL_BRUTE)
+        assert sc.traversal(0, tr, 400, 400) == 0
