@@ -330,6 +330,9 @@ __device__ __forceinline__ Hit cast_ray_packet(const DevScene& sc, int oct, vec3
 	c4ptr rec;
 	rec.p = (const __attribute__((address_space(4))) v4f*)(unsigned long long)sc.skiplist;
 	rec = rec.offset_floats((long long)oct * sc.skip_count * 16);
+#ifdef RT_PROFILE
+	int steps_ = 0;
+#endif
 	int stackv = 0;          // wave-uniform stack: entry k lives in lane k (a Karras tree over 63 key bits is at most 63 deep)
 	int sp = 0;
 	int node = 0;
@@ -363,7 +366,16 @@ __device__ __forceinline__ Hit cast_ray_packet(const DevScene& sc, int oct, vec3
 			next = __builtin_amdgcn_readlane(stackv, sp);
 		}
 		node = next;
+#ifdef RT_PROFILE
+		steps_++;
+#endif
 	}
+#ifdef RT_PROFILE
+	if (wp.g && __builtin_ctzll(__builtin_amdgcn_ballot_w64(true)) == (int)__lane_id()) {   // histogram of node steps per walk: counters 20..27
+		const int b = steps_ < 16 ? 0 : steps_ < 32 ? 1 : steps_ < 48 ? 2 : steps_ < 64 ? 3 : steps_ < 96 ? 4 : steps_ < 128 ? 5 : steps_ < 192 ? 6 : 7;
+		atomicAdd(&wp.g[20 + b], 1ull);
+	}
+#endif
 	return h;
 }
 
