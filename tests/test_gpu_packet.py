@@ -135,3 +135,9 @@ def test_launcher_choice_is_reported():
         assert sc.traversal(0, tr, 3840, 2160) == api.TRAVERSAL_PER_LANE
         sc.commit(0, api.ACCEL_BRUTE)
         assert sc.traversal(0, tr, 400, 400) == 0
+
+
+@pytest.mark.parametrize("n", [2, 3, 5, 9])
+def test_smallest_trees_through_packets(oracle, n):
+    desc = _soup(40 + n, n, 4.0, w=40, h=24, depth=3, lights=2)
+    assert np.array_equal(_bits(_lbvh_frame(desc)), _bits(oracle.render_desc(desc)))
