@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=512)
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--workload", default="room800",
-                    choices=["room800", "stock800", "mirrors4k", "spheres800", "spheres4k", "sweep8k"])
+                    choices=["room800", "stock800", "mirrors4k", "spheres800", "spheres4k", "sweep8k", "sweep8k_spheres"])
     ap.add_argument("--mode", default="strict", choices=["strict", "fast"])
     ap.add_argument("--tiles-per-wave", type=int, default=0)
     ap.add_argument("--frames-per-launch", type=int, default=32,
@@ -76,6 +76,8 @@ def make_workload(name):
         return scenes.spheres(20, 4, 3840, 2160), "lbvh", "102412 triangles, 3840x2160, LBVH"
     if name == "sweep8k":
         return scenes.room(7680, 4320), "brute", "README room scene 7680x4320, 64-pose sweep, interleaved row tiles + gather"
+    if name == "sweep8k_spheres":
+        return scenes.spheres(20, 4, 7680, 4320), "lbvh", "102412 triangles 7680x4320, 64-pose sweep, LBVH, interleaved row tiles + gather"
     raise ValueError(name)
 
 
@@ -171,7 +173,7 @@ def main():
 
     # work per pose (rays and algorithmic FLOPs), counted by the instrumented kernel outside the
     # timed region; identical to the oracle's counters (tests/test_gpu_parity.py)
-    tile_mode = args.workload == "sweep8k" and world > 1
+    tile_mode = args.workload.startswith("sweep8k") and world > 1
     if tile_mode:
         my_frames = [s % 64 for s in range(args.steps)]         # every rank works on the same frame
     else:
