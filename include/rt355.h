@@ -106,8 +106,15 @@ int rt_scene_build_ms(const rt_scene* s, int device, float* out_ms);
 /* Copy out the LBVH built by the last commit on `device` (tests, tools): up to `capacity` nodes of
  * 16 floats each — {left box lo xyz, hi xyz, right box lo xyz, hi xyz, left ref, right ref, 0, 0},
  * refs as int bits: >= 0 internal node index, < 0 leaf holding triangle ~ref; node 0 is the root.
- * Returns the number of nodes (triangle count - 1), or 0 for a brute-force commit. */
+ * Returns the number of nodes (triangles in the tree - 1), or 0 for a brute-force commit. */
 int rt_scene_get_bvh(const rt_scene* s, int device, float* out_nodes16, int capacity);
+
+/* The triangles the last LBVH commit on `device` kept OUT of the tree: those whose box has an
+ * eighth or more of the scene box's surface area (walls, a ground plane; at most 32).  Every ray
+ * tests them directly before it walks the tree, as castRay's loop would (Src:301-401); inside the
+ * tree each would widen every box on its path to the root.  Copies up to `capacity` ascending
+ * triangle indices; returns how many there are (0 for a brute-force commit). */
+int rt_scene_get_hoisted(const rt_scene* s, int device, int* out_indices, int capacity);
 
 /* The acceleration structure the last commit on `device` chose: RT_ACCEL_BRUTE or RT_ACCEL_LBVH. */
 int rt_scene_accel(const rt_scene* s, int device);

@@ -33,7 +33,7 @@ SYMBOLS = (
     "rt_scene_create", "rt_scene_destroy", "rt_scene_clear", "rt_scene_add_triangle",
     "rt_scene_add_triangles", "rt_scene_add_quad_half", "rt_scene_add_light", "rt_scene_load_rto",
     "rt_scene_triangle_count", "rt_scene_light_count", "rt_scene_get_triangles", "rt_scene_commit",
-    "rt_scene_build_ms", "rt_scene_get_bvh", "rt_scene_accel", "rt_camera_trans", "rt_camera_init", "rt_camera_rotate",
+    "rt_scene_build_ms", "rt_scene_get_bvh", "rt_scene_get_hoisted", "rt_scene_accel", "rt_camera_trans", "rt_camera_init", "rt_camera_rotate",
     "rt_camera_translate", "rt_camera_frame_time", "rt_camera_step", "rt_camera_path", "rt_render", "rt_render_device",
     "rt_render_frames_device", "rt_render_tiles_device", "rt_shard_rows", "rt_render_stats", "rt_render_multi", "rt_cast_rays",
     "rt_device_count", "rt_set_tiles_per_wave", "rt_set_traversal", "rt_scene_traversal", "rt_last_error", "rt_version",
@@ -124,6 +124,7 @@ def lib():
     L.rt_scene_build_ms.argtypes = [vp, ci, _fp]
     L.rt_scene_accel.argtypes = [vp, ci]
     L.rt_scene_get_bvh.argtypes = [vp, ci, _fp, ci]
+    L.rt_scene_get_hoisted.argtypes = [vp, ci, C.POINTER(C.c_int), ci]
     L.rt_camera_trans.argtypes = [_fp, _fp]
     cp = C.POINTER(CameraState)
     L.rt_camera_init.argtypes = [cp, _fp, _fp]
@@ -358,11 +359,19 @@ class Scene:
         return _check(lib().rt_scene_accel(self._h, int(device)))
 
     def bvh(self, device: int = 0) -> np.ndarray:
-        """(N-1, 16) float32 LBVH nodes (see rt_scene_get_bvh); empty for a brute-force commit."""
+        """(triangles in the tree - 1, 16) float32 LBVH nodes (see rt_scene_get_bvh); empty for a brute-force commit."""
         n = _check(lib().rt_scene_get_bvh(self._h, int(device), None, 0))
         out = np.zeros((n, 16), dtype=np.float32)
         if n:
             _check(lib().rt_scene_get_bvh(self._h, int(device), _p(out), n))
+        return out
+
+    def hoisted(self, device: int = 0) -> np.ndarray:
+        """Indices of the triangles an LBVH commit kept out of the tree (rt_scene_get_hoisted)."""
+        n = _check(lib().rt_scene_get_hoisted(self._h, int(device), None, 0))
+        out = np.zeros(n, dtype=np.int32)
+        if n:
+            _check(lib().rt_scene_get_hoisted(self._h, int(device), out.ctypes.data_as(C.POINTER(C.c_int)), n))
         return out
 
     def build_ms(self, device: int = 0) -> float:

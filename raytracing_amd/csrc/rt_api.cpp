@@ -245,7 +245,7 @@ int rt_scene_get_bvh(const rt_scene* s, int device, float* out_nodes16, int capa
 	if (it == s->dev.end() || !it->second.valid) { set_error("rt_scene_get_bvh: not committed on device %d", device); return RT_ERR_STATE; }
 	const DeviceState& d = it->second;
 	if (d.accel != RT_ACCEL_LBVH || !d.bvh_nodes) return 0;
-	const int nodes = (int)(s->tris.size() / RT_TRI_FLOATS) - 1;
+	const int nodes = d.bvh_node_count;
 	const int k = nodes < capacity ? nodes : capacity;
 	if (k > 0) {
 		DeviceGuard g(device);
@@ -253,6 +253,17 @@ int rt_scene_get_bvh(const rt_scene* s, int device, float* out_nodes16, int capa
 		RT_HIP(hipMemcpy(out_nodes16, d.bvh_nodes, (size_t)k * 16 * sizeof(float), hipMemcpyDeviceToHost));
 	}
 	return nodes;
+}
+
+int rt_scene_get_hoisted(const rt_scene* s, int device, int* out_indices, int capacity) {
+	if (!s || capacity < 0 || (capacity > 0 && !out_indices)) { set_error("rt_scene_get_hoisted: bad argument"); return RT_ERR_INVALID; }
+	auto it = s->dev.find(device);
+	if (it == s->dev.end() || !it->second.valid) { set_error("rt_scene_get_hoisted: not committed on device %d", device); return RT_ERR_STATE; }
+	const DeviceState& d = it->second;
+	if (d.accel != RT_ACCEL_LBVH) return 0;
+	const int nh = (int)d.hoisted.size();
+	for (int j = 0; j < nh && j < capacity; j++) out_indices[j] = d.hoisted[j];
+	return nh;
 }
 
 int rt_scene_accel(const rt_scene* s, int device) {

@@ -39,6 +39,9 @@ enum { PL_N = 0, PL_P1, PL_P2, PL_P3, PL_E0, PL_E1, PL_E2, PL_GLO, PL_GHI, PL_CL
 // (ACCEL 1).  The scene itself is read through the scalar cache in both.
 #define RT_LDS_MAX_TRIS 1024
 
+// LBVH: at most this many scene-spanning triangles are hoisted out of the tree (DevScene::hoist)
+#define RT_HOIST_MAX 32
+
 struct DevScene {
 	const float4* planes;   // PL_COUNT * stride float4
 	const float4* lights;   // n_lights x (pos.xyz, intensity)   Source.cpp:69-73
@@ -56,6 +59,13 @@ struct DevScene {
 	// per octant and inner node one 64-byte record with BOTH children, the one nearer along the
 	// octant first: (nearA.xyz, farA.xyz, refA, refB, nearB.xyz, farB.xyz, -, -).
 	const float4* skiplist;
+	// Triangles whose box spans a large part of the scene (walls, a ground plane) are kept OUT of
+	// the tree, where each would inflate every box on its path to the root, and are tested first
+	// for every ray from this list (rt_lbvh.hip lbvh_build): hoist_count records of 8 float4 as in
+	// tri_aos, ascending by triangle index, then for each of the 8 octants hoist_count padded boxes
+	// of 8 floats (near.xyz, far.xyz, -, triangle index as int bits) as in the octant records above.
+	const float4* hoist;
+	int hoist_count;
 	// Octant-ordered copies of the group and cluster boxes (brute force): for each of the 8 sign
 	// combinations of a ray direction, entry e is 8 floats (near.xyz, far.xyz, a, b) where near/far
 	// are the box faces a ray of that octant meets first/last per axis; clusters carry a = first
@@ -103,6 +113,10 @@ struct DeviceState {
 	void* tri_aos = nullptr;
 	void* skiplist = nullptr;
 	int skip_count = 0;
+	void* hoist = nullptr;
+	int hoist_count = 0;
+	int bvh_node_count = 0;      // inner nodes of the binary tree (triangles in the tree - 1)
+	std::vector<int> hoisted;    // triangle indices kept out of the tree, ascending
 	float packet_scale = 0.f;
 	void* counters = nullptr;
 	int bvh_root = 0;

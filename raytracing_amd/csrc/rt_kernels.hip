@@ -289,12 +289,9 @@ __device__ __forceinline__ Hit cast_ray_pruned(const DevScene& sc, c4ptr tri, in
 // farther inner child waits on a wave-uniform stack kept in the lanes of one VGPR.  No per-lane
 // stack, no sorting, no divergence, every load scalar.  The order of visits is not the index order,
 // so ties go to the lower index explicitly (as in rt_lbvh_trav.inl).
-__device__ __forceinline__ void packet_leaf(const DevScene& sc, int i, vec3 o, vec3 d, int skip, bool first_only,
+__device__ __forceinline__ void packet_leaf(c4ptr T, int i, vec3 o, vec3 d, int skip, bool first_only,
                                             float eps_lo, Hit& h, float& lim, float& lim_hi, WaveProf& wp) {
 	RT_PROF(wp, WP_TRI);
-	c4ptr T;
-	T.p = (const __attribute__((address_space(4))) v4f*)(unsigned long long)sc.tri_aos;
-	T = T.offset_floats((long long)i * 32);
 	const float4 N4 = T[0], P14 = T[1];
 	const vec3 nn = xyz(N4), p1 = xyz(P14);
 	const float num = dot(p1 - o, nn);
@@ -330,9 +327,25 @@ __device__ __forceinline__ Hit cast_ray_packet(const DevScene& sc, int oct, vec3
 	c4ptr rec;
 	rec.p = (const __attribute__((address_space(4))) v4f*)(unsigned long long)sc.skiplist;
 	rec = rec.offset_floats((long long)oct * sc.skip_count * 16);
+	c4ptr aos;
+	aos.p = (const __attribute__((address_space(4))) v4f*)(unsigned long long)sc.tri_aos;
 #ifdef RT_PROFILE
 	int steps_ = 0;
 #endif
+	if (sc.hoist_count > 0) {
+		// the triangles kept out of the tree (DevScene::hoist), each behind its octant-ordered box
+		c4ptr hrec;
+		hrec.p = (const __attribute__((address_space(4))) v4f*)(unsigned long long)sc.hoist;
+		const c4ptr hbox = hrec.offset_floats((long long)sc.hoist_count * 32 + (long long)oct * sc.hoist_count * 8);
+		for (int j = 0; j < sc.hoist_count; j++) {
+			const c4ptr R = hbox.offset_floats((long long)j * 8);
+			const float4 a0 = R[0], a1 = R[1];
+			RT_PROF(wp, WP_INBOX);
+			if (__builtin_amdgcn_ballot_w64(slab_hit_oct(a0, a1, inv, oi, lim_hi)) != 0)
+				packet_leaf(hrec.offset_floats((long long)j * 32), __float_as_int(a1.w), o, d, skip, first_only, eps_lo, h, lim, lim_hi, wp);
+		}
+		if (__builtin_amdgcn_ballot_w64(lim >= 0.0f) == 0) return h;            // (shadow rays that all have their hit)
+	}
 	int stackv = 0;          // wave-uniform stack: entry k lives in lane k (a Karras tree over 63 key bits is at most 63 deep)
 	int sp = 0;
 	int node = 0;
@@ -344,13 +357,13 @@ __device__ __forceinline__ Hit cast_ray_packet(const DevScene& sc, int oct, vec3
 		const bool hitA = __builtin_amdgcn_ballot_w64(slab_hit_oct(q0, q1, inv, oi, lim_hi)) != 0;
 		int next = -1;
 		if (hitA) {
-			if (refA < 0) packet_leaf(sc, ~refA, o, d, skip, first_only, eps_lo, h, lim, lim_hi, wp);
+			if (refA < 0) packet_leaf(aos.offset_floats((long long)(~refA) * 32), ~refA, o, d, skip, first_only, eps_lo, h, lim, lim_hi, wp);
 			else next = refA;
 		}
 		// the farther child is tested after a near LEAF has had its chance to shorten the limits
 		const bool hitB = __builtin_amdgcn_ballot_w64(slab_hit_oct(q2, q3, inv, oi, lim_hi)) != 0;
 		if (hitB) {
-			if (refB < 0) packet_leaf(sc, ~refB, o, d, skip, first_only, eps_lo, h, lim, lim_hi, wp);
+			if (refB < 0) packet_leaf(aos.offset_floats((long long)(~refB) * 32), ~refB, o, d, skip, first_only, eps_lo, h, lim, lim_hi, wp);
 			else if (next >= 0) {
 				// v_writelane with a scalar value takes its lane index from m0 (one constant-bus operand); m0 is put back
 				int m0_saved;
@@ -377,6 +390,46 @@ __device__ __forceinline__ Hit cast_ray_packet(const DevScene& sc, int oct, vec3
 	}
 #endif
 	return h;
+}
+
+// ---- the triangles kept out of the tree (DevScene::hoist), for the per-lane traversal ------------
+// Tested for every ray before the walk, from scalar loads, in index order with the reference's own
+// strict comparison (Source.cpp:391), each behind a test of its own padded box (skipped when no ray
+// of the wave meets it); the walk then starts from the hit and limit they leave.
+template <bool COUNT>
+__device__ __forceinline__ void hoisted_tests(const DevScene& sc, vec3 o, vec3 d, vec3 inv, vec3 oi, int skip, bool live, bool first_only,
+                                              Hit& h, float& lim, float& lim_hi, LaneCounters& lc, WaveProf& wp) {
+	c4ptr T;
+	T.p = (const __attribute__((address_space(4))) v4f*)(unsigned long long)sc.hoist;
+	c4ptr B = T.offset_floats((long long)sc.hoist_count * 32);                           // octant 0: near = lo, far = hi
+	for (int j = 0; j < sc.hoist_count; j++, T = T.offset_floats(32), B = B.offset_floats(8)) {
+		const float4 b0 = B[0], b1 = B[1];
+		if constexpr (COUNT) lc.box += live;
+		if (__builtin_amdgcn_ballot_w64(live && slab_hit(b0, make_float4(b0.w, b1.x, b1.y, 0.f), inv, oi, lim_hi)) == 0) continue;
+		RT_PROF(wp, WP_TRI);
+		const int i = __float_as_int(b1.w);
+		const float4 N4 = T[0], P14 = T[1];
+		const vec3 nn = xyz(N4), p1 = xyz(P14);
+		const float t = dot(p1 - o, nn) / dot(d, nn);                           // Source.cpp:383
+		const bool visit = live && i != skip;                                   // Source.cpp:302
+		const bool cand = visit && (t > RT_EPS_BELOW) && (t < lim);             // Source.cpp:385, 391
+		if constexpr (COUNT) { lc.plane += visit; lc.point += visit && !(t < 0.0f); lc.edge += cand; }
+		if (__builtin_amdgcn_ballot_w64(cand) == 0) continue;
+		const float4 P24 = T[2], P34 = T[3], E0 = T[4], E1 = T[5], E2 = T[6];
+		const vec3 I = make3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);      // Source.cpp:389
+		const bool c0 = cand && (dot(nn, cross(xyz(E0), I - p1)) > 0.0f);       // Source.cpp:392
+		if constexpr (COUNT) lc.edge += c0;
+		if (__builtin_amdgcn_ballot_w64(c0) == 0) continue;
+		const bool c1 = c0 && (dot(nn, cross(xyz(E1), I - xyz(P24))) > 0.0f);   // Source.cpp:393
+		if constexpr (COUNT) lc.edge += c1;
+		if (__builtin_amdgcn_ballot_w64(c1) == 0) continue;
+		const bool c2 = c1 && (dot(nn, cross(xyz(E2), I - xyz(P34))) > 0.0f);   // Source.cpp:394
+		if (c2) {                                                               // Source.cpp:396
+			h.t = t; h.idx = i; h.p = I;
+			lim = first_only ? -1.0f : t;
+			lim_hi = lim + fabsf(lim) * RT_PREFILTER_REL;
+		}
+	}
 }
 
 // Upper bound on the distance of any hit: where the ray leaves the (padded) scene box.
@@ -835,6 +888,8 @@ DevScene dev_scene(const rt_scene* s, const DeviceState& d) {
 	sc.bvh_root = d.bvh_root;
 	sc.skip_count = d.skip_count;
 	sc.skiplist = (const float4*)d.skiplist;
+	sc.hoist = (const float4*)d.hoist;
+	sc.hoist_count = d.hoist_count;
 	sc.far_guard = d.far_guard;
 	sc.packet_scale = d.packet_scale;
 	for (int k = 0; k < 3; k++) { sc.bb_lo[k] = d.bb_lo[k]; sc.bb_hi[k] = d.bb_hi[k]; }

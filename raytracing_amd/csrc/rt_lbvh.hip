@@ -316,6 +316,68 @@ __global__ void __launch_bounds__(256) k_packet(const float4* __restrict__ nodes
 	}
 }
 
+// 8. hoisted triangles (DevScene::hoist): their keys get the top bit, so they sort behind every
+//    triangle of the tree; their records are copied out in index order, followed by their padded
+//    boxes ordered near/far for each octant.
+__global__ void __launch_bounds__(64) k_hoist(const float4* __restrict__ planes, int stride, const int* __restrict__ idx, int k, float pad,
+                                             u64* __restrict__ keys, float4* __restrict__ out) {
+	const int j = threadIdx.x;
+	if (j >= k) return;
+	float4* boxes = out + (size_t)k * 8;
+	const int i = idx[j];
+	keys[i] = (1ull << 63) | (u64)(unsigned int)i;
+	float4* o = out + (size_t)j * 8;
+	o[0] = planes[PL_N * stride + i];
+	o[1] = planes[PL_P1 * stride + i];
+	o[2] = planes[PL_P2 * stride + i];
+	o[3] = planes[PL_P3 * stride + i];
+	o[4] = planes[PL_E0 * stride + i];
+	o[5] = planes[PL_E1 * stride + i];
+	o[6] = planes[PL_E2 * stride + i];
+	o[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+	float lo[3], hi[3];
+	tri_box(planes, stride, i, lo, hi);
+	for (int a = 0; a < 3; a++) { lo[a] -= pad; hi[a] += pad; }
+	for (int oct = 0; oct < 8; oct++) {
+		float nr[3], fr[3];
+		for (int a = 0; a < 3; a++) {
+			const bool neg = (oct >> a) & 1;
+			nr[a] = neg ? hi[a] : lo[a];
+			fr[a] = neg ? lo[a] : hi[a];
+		}
+		boxes[((size_t)oct * k + j) * 2] = make_float4(nr[0], nr[1], nr[2], fr[0]);
+		boxes[((size_t)oct * k + j) * 2 + 1] = make_float4(fr[1], fr[2], 0.f, __int_as_float(i));
+	}
+}
+
+// Which triangles stay out of the tree: those whose vertex box has at least an eighth of the
+// surface area of the scene's box.  A ray meets such a box with that probability or more at every
+// level of the path from its leaf to the root, so leaving it in costs more box tests than the one
+// triangle test per ray that hoisting costs.  At most RT_HOIST_MAX of them and a quarter of the
+// scene (beyond that the scene is made of large triangles and the tree is what it is).
+void pick_hoisted(const std::vector<float>& tris, const float bb_lo[3], const float bb_hi[3], std::vector<int>& out) {
+	out.clear();
+	const int n = (int)(tris.size() / RT_TRI_FLOATS);
+	if (std::getenv("RT355_NO_HOIST")) return;
+	const double ex = (double)bb_hi[0] - bb_lo[0], ey = (double)bb_hi[1] - bb_lo[1], ez = (double)bb_hi[2] - bb_lo[2];
+	const double scene_area = ex * ey + ey * ez + ez * ex;
+	if (!(scene_area > 0.0) || !(scene_area < 1e300)) return;
+	for (int i = 0; i < n; i++) {
+		const float* v = tris.data() + (size_t)i * RT_TRI_FLOATS + 6;      // p1 p2 p3
+		double e[3];
+		for (int k = 0; k < 3; k++) {
+			const float lo = fminf(v[k], fminf(v[3 + k], v[6 + k])), hi = fmaxf(v[k], fmaxf(v[3 + k], v[6 + k]));
+			e[k] = (double)hi - (double)lo;
+		}
+		const double area = e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
+		if (area * 8.0 >= scene_area) {
+			if ((int)out.size() == RT_HOIST_MAX) { out.clear(); return; }
+			out.push_back(i);
+		}
+	}
+	if ((long long)out.size() * 4 > n || n - (int)out.size() < 2) out.clear();
+}
+
 template <typename T>
 int dev_alloc(T** p, size_t count) {
 	hipError_t e = hipMalloc((void**)p, count * sizeof(T));
@@ -330,6 +392,11 @@ void lbvh_free(DeviceState& d) {
 	if (d.bvh4) (void)hipFree(d.bvh4);
 	if (d.tri_aos) (void)hipFree(d.tri_aos);
 	if (d.skiplist) (void)hipFree(d.skiplist);
+	if (d.hoist) (void)hipFree(d.hoist);
+	d.hoist = nullptr;
+	d.hoist_count = 0;
+	d.bvh_node_count = 0;
+	d.hoisted.clear();
 	d.bvh_nodes = nullptr;
 	d.bvh4 = nullptr;
 	d.tri_aos = nullptr;
@@ -346,6 +413,13 @@ int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 			return RT_ERR_LIMIT;
 		}
 	lbvh_free(d);
+	std::vector<int> hoisted;
+	pick_hoisted(s->tris, d.bb_lo, d.bb_hi, hoisted);
+	const int nh = (int)hoisted.size();
+	const int nt = n - nh;                       // triangles in the tree
+	const size_t hoist_float4s = (size_t)nh * (8 + 8 * 2);   // records, then 8 octants of boxes
+	int* hoist_idx = nullptr;
+	float4* hoist = nullptr;
 	u64 *keys = nullptr, *keys_sorted = nullptr;
 	int *parent_int = nullptr, *parent_leaf = nullptr;
 	unsigned int* flags = nullptr;
@@ -361,54 +435,79 @@ int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 		if (parent_leaf) (void)hipFree(parent_leaf);
 		if (flags) (void)hipFree(flags);
 		if (temp) (void)hipFree(temp);
+		if (hoist_idx) (void)hipFree(hoist_idx);
 		if (e0) (void)hipEventDestroy(e0);
 		if (e1) (void)hipEventDestroy(e1);
 	};
-#define LB_TRY(x) do { rc = (x); if (rc != RT_OK) { cleanup(); if (nodes) (void)hipFree(nodes); if (nodes4) (void)hipFree(nodes4); if (aos) (void)hipFree(aos); if (pkt) (void)hipFree(pkt); return rc; } } while (0)
-#define LB_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = hip_fail(e_, #x); cleanup(); if (nodes) (void)hipFree(nodes); if (nodes4) (void)hipFree(nodes4); if (aos) (void)hipFree(aos); if (pkt) (void)hipFree(pkt); return rc; } } while (0)
+#define LB_TRY(x) do { rc = (x); if (rc != RT_OK) { cleanup(); if (nodes) (void)hipFree(nodes); if (nodes4) (void)hipFree(nodes4); if (aos) (void)hipFree(aos); if (pkt) (void)hipFree(pkt); if (hoist) (void)hipFree(hoist); return rc; } } while (0)
+#define LB_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = hip_fail(e_, #x); cleanup(); if (nodes) (void)hipFree(nodes); if (nodes4) (void)hipFree(nodes4); if (aos) (void)hipFree(aos); if (pkt) (void)hipFree(pkt); if (hoist) (void)hipFree(hoist); return rc; } } while (0)
 	LB_TRY(dev_alloc(&keys, (size_t)n));
 	LB_TRY(dev_alloc(&keys_sorted, (size_t)n));
 	LB_TRY(dev_alloc(&parent_int, (size_t)n));
 	LB_TRY(dev_alloc(&parent_leaf, (size_t)n));
 	LB_TRY(dev_alloc(&flags, (size_t)n));
-	LB_TRY(dev_alloc(&nodes, (size_t)(n - 1) * 4));
-	LB_TRY(dev_alloc(&nodes4, (size_t)(n - 1) * 4));
+	LB_TRY(dev_alloc(&nodes, (size_t)(nt - 1) * 4));
+	LB_TRY(dev_alloc(&nodes4, (size_t)(nt - 1) * 4));
 	LB_TRY(dev_alloc(&aos, (size_t)n * 8));
 	const bool want_packet = true;
-	LB_TRY(dev_alloc(&pkt, (size_t)(n - 1) * 4 * 8));
+	LB_TRY(dev_alloc(&pkt, (size_t)(nt - 1) * 4 * 8));
+	if (nh > 0) {
+		LB_TRY(dev_alloc(&hoist_idx, (size_t)nh));
+		LB_TRY(dev_alloc(&hoist, hoist_float4s));
+		LB_HIP(hipMemcpy(hoist_idx, hoisted.data(), (size_t)nh * sizeof(int), hipMemcpyHostToDevice));
+	}
 	size_t temp_bytes = 0;
 	int index_bits = 1;
 	while (index_bits < 31 && (1ll << index_bits) < (long long)n) index_bits++;
 	const unsigned int index_mask = (unsigned int)((1ull << index_bits) - 1ull);
-	const unsigned int key_bits = (unsigned int)((63 - index_bits) / 3 * 3 + index_bits);
+	const unsigned int key_bits = nh > 0 ? 64u : (unsigned int)((63 - index_bits) / 3 * 3 + index_bits);   // bit 63: hoisted
 	LB_HIP(rocprim::radix_sort_keys(nullptr, temp_bytes, keys, keys_sorted, (size_t)n, 0, key_bits, stream));
 	LB_HIP(hipMalloc(&temp, temp_bytes > 0 ? temp_bytes : 16));
 	LB_HIP(hipEventCreate(&e0));
 	LB_HIP(hipEventCreate(&e1));
 
+	// Morton codes are taken over the box of the triangles that go into the tree
 	BoxF scene;
 	for (int k = 0; k < 3; k++) { scene.lo[k] = d.bb_lo[k]; scene.hi[k] = d.bb_hi[k]; }
+	if (nh > 0) {
+		for (int k = 0; k < 3; k++) { scene.lo[k] = __builtin_huge_valf(); scene.hi[k] = -__builtin_huge_valf(); }
+		size_t next = 0;
+		for (int i = 0; i < n; i++) {
+			if (next < hoisted.size() && hoisted[next] == i) { next++; continue; }
+			const float* v = s->tris.data() + (size_t)i * RT_TRI_FLOATS + 6;
+			for (int k = 0; k < 3; k++) {
+				scene.lo[k] = fminf(scene.lo[k], fminf(v[k], fminf(v[3 + k], v[6 + k])));
+				scene.hi[k] = fmaxf(scene.hi[k], fmaxf(v[k], fmaxf(v[3 + k], v[6 + k])));
+			}
+		}
+	}
 	const float pad = d.pad;
 	const float4* planes = (const float4*)d.planes;
 	const unsigned int blocks_n = (unsigned int)((n + 255) / 256);
+	const unsigned int blocks_t = (unsigned int)((nt + 255) / 256);
 
 	LB_HIP(hipEventRecord(e0, stream));
 	LB_HIP(hipMemsetAsync(flags, 0, (size_t)n * sizeof(unsigned int), stream));
-	LB_HIP(hipMemsetAsync(nodes, 0, (size_t)(n - 1) * 4 * sizeof(float4), stream));
+	LB_HIP(hipMemsetAsync(nodes, 0, (size_t)(nt - 1) * 4 * sizeof(float4), stream));
 	hipLaunchKernelGGL(k_morton, dim3(blocks_n), dim3(256), 0, stream, planes, d.stride, n, scene, index_bits, keys);
 	LB_HIP(hipGetLastError());
+	if (nh > 0) {
+		hipLaunchKernelGGL(k_hoist, dim3(1), dim3(64), 0, stream, planes, d.stride, (const int*)hoist_idx, nh, pad, keys, hoist);
+		LB_HIP(hipGetLastError());
+	}
 	LB_HIP(rocprim::radix_sort_keys(temp, temp_bytes, keys, keys_sorted, (size_t)n, 0, key_bits, stream));
-	hipLaunchKernelGGL(k_karras, dim3(blocks_n), dim3(256), 0, stream, keys_sorted, n, index_mask, nodes, parent_int, parent_leaf);
+	// (the hoisted keys sorted to the tail: the tree is built over the first nt)
+	hipLaunchKernelGGL(k_karras, dim3(blocks_t), dim3(256), 0, stream, keys_sorted, nt, index_mask, nodes, parent_int, parent_leaf);
 	LB_HIP(hipGetLastError());
-	hipLaunchKernelGGL(k_refit, dim3(blocks_n), dim3(256), 0, stream, planes, d.stride, n, keys_sorted, index_mask, (float*)nodes,
+	hipLaunchKernelGGL(k_refit, dim3(blocks_t), dim3(256), 0, stream, planes, d.stride, nt, keys_sorted, index_mask, (float*)nodes,
 	                   parent_int, parent_leaf, flags, pad);
 	LB_HIP(hipGetLastError());
-	hipLaunchKernelGGL(k_collapse4, dim3(blocks_n), dim3(256), 0, stream, (const float4*)nodes, n - 1, nodes4);
+	hipLaunchKernelGGL(k_collapse4, dim3(blocks_t), dim3(256), 0, stream, (const float4*)nodes, nt - 1, nodes4);
 	LB_HIP(hipGetLastError());
 	hipLaunchKernelGGL(k_aos, dim3(blocks_n), dim3(256), 0, stream, planes, d.stride, n, aos);
 	LB_HIP(hipGetLastError());
 	if (want_packet) {
-		hipLaunchKernelGGL(k_packet, dim3(blocks_n), dim3(256), 0, stream, (const float4*)nodes, n - 1, pkt);
+		hipLaunchKernelGGL(k_packet, dim3(blocks_t), dim3(256), 0, stream, (const float4*)nodes, nt - 1, pkt);
 		LB_HIP(hipGetLastError());
 	}
 	LB_HIP(hipEventRecord(e1, stream));
@@ -425,6 +524,7 @@ int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 		(void)hipFree(nodes4);
 		(void)hipFree(aos);
 		if (pkt) (void)hipFree(pkt);
+		if (hoist) (void)hipFree(hoist);
 		return RT_ERR_DEVICE;
 	}
 #undef LB_TRY
@@ -434,7 +534,11 @@ int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 	d.bvh4 = nodes4;
 	d.tri_aos = aos;
 	d.skiplist = pkt;
-	d.skip_count = pkt ? n - 1 : 0;
+	d.skip_count = pkt ? nt - 1 : 0;
+	d.hoist = hoist;
+	d.hoist_count = nh;
+	d.bvh_node_count = nt - 1;
+	d.hoisted = hoisted;
 	d.bvh_root = 0;
 	d.build_ms = ms;
 	return RT_OK;

@@ -64,11 +64,16 @@ __device__ __forceinline__ Hit cast_ray_lbvh(const DevScene& sc, int* lds_stack,
 	lim = fminf(lim, 1e9f);
 	float lim_hi = lim + fabsf(lim) * RT_PREFILTER_REL;
 	if (!cull) { s.inv = make3(0.f, 0.f, 0.f); s.oi = make3(0.f, 0.f, 0.f); }           // every (non-empty) box tests as hit
+	bool walk = live;
+	if (sc.hoist_count > 0) {
+		hoisted_tests<COUNT>(sc, o, d, s.inv, s.oi, skip, live, shadow, h, lim, lim_hi, lc, wp);
+		walk = live && lim >= 0.0f;                                      // a shadow ray that has its hit is done
+	}
 	const int SENT = 0x7fffffff;
 	const int tid = threadIdx.x;
 	int ovf[RT_STACK_MAX - RT_STACK_LDS];
 	int sp = 0;
-	int node = live ? sc.bvh_root : SENT;
+	int node = walk ? sc.bvh_root : SENT;
 	int* const slot0 = lds_stack + tid;                                  // entry k of this lane: slot0[k * RT_STACK_PITCH]
 
 	// General stack access (any depth); the loop below uses it only when some lane of the wave is

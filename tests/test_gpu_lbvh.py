@@ -18,14 +18,15 @@ def _bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
 
-def _check_tree(nodes, tris):
+def _check_tree(nodes, tris, hoisted=()):
     """2N-1 nodes, every leaf reachable exactly once, child boxes inside the parent's slot for
-    them, every leaf box containing its triangle."""
+    them, every leaf box containing its triangle; the hoisted triangles (kept out of the tree,
+    rt_scene_get_hoisted) are in no leaf."""
     n = tris.shape[0]
-    assert nodes.shape == (n - 1, 16)
+    assert nodes.shape == (n - len(hoisted) - 1, 16)
     refs = nodes[:, 12:14].copy().view(np.int32)
     seen_leaf = np.zeros(n, dtype=np.int32)
-    seen_node = np.zeros(n - 1, dtype=np.int32)
+    seen_node = np.zeros(nodes.shape[0], dtype=np.int32)
     seen_node[0] = 1
     stack = [(0, None)]
     max_depth = 0
@@ -45,14 +46,16 @@ def _check_tree(nodes, tris):
                 v = tris[t, 6:15].reshape(3, 3)
                 assert np.all(v.min(axis=0) >= box_lo) and np.all(v.max(axis=0) <= box_hi)
             else:
-                assert 0 < r < n - 1
+                assert 0 < r < nodes.shape[0]
                 seen_node[r] += 1
                 child_lo = np.minimum(nodes[r, 0:3], nodes[r, 6:9])
                 child_hi = np.maximum(nodes[r, 3:6], nodes[r, 9:12])
                 assert np.all(child_lo >= box_lo) and np.all(child_hi <= box_hi)   # parent box == union of children
                 assert np.array_equal(child_lo, box_lo) and np.array_equal(child_hi, box_hi)
                 stack.append((r, depth))
-    assert np.all(seen_leaf == 1) and np.all(seen_node == 1)
+    in_tree = np.ones(n, dtype=np.int32)
+    in_tree[np.asarray(hoisted, dtype=np.int64)] = 0
+    assert np.array_equal(seen_leaf, in_tree) and np.all(seen_node == 1)
     return max_depth
 
 
@@ -61,9 +64,64 @@ def test_tree_invariants():
         with api.Scene.from_desc(desc) as sc:
             sc.commit(0, api.ACCEL_LBVH)
             assert sc.accel(0) == api.ACCEL_LBVH
-            depth = _check_tree(sc.bvh(0), sc.triangles())
+            depth = _check_tree(sc.bvh(0), sc.triangles(), sc.hoisted(0))
             assert depth <= 62
             assert sc.build_ms(0) > 0
+
+
+def _box_area(tris):
+    v = tris[:, 6:15].reshape(-1, 3, 3)
+    e = (v.max(axis=1) - v.min(axis=1)).astype(np.float64)
+    return e[:, 0] * e[:, 1] + e[:, 1] * e[:, 2] + e[:, 2] * e[:, 0]
+
+
+def test_scene_spanning_triangles_are_hoisted(oracle):
+    """The room's 12 wall triangles around tessellated spheres stay out of the tree (each would
+    widen every box on its path to the root); frames are the same bits with and without them in
+    the tree, for both traversals, and equal the oracle's."""
+    desc = scenes.spheres(3, 2, 96, 64, depth=2)
+    with api.Scene.from_desc(desc) as sc:
+        sc.commit(0, api.ACCEL_LBVH)
+        tris = sc.triangles()
+        h = sc.hoisted(0)
+        assert h.tolist() == list(range(12))                      # _room() comes first in the scene
+        v = tris[:, 6:15].reshape(-1, 3, 3)
+        ext = (v.max(axis=(0, 1)) - v.min(axis=(0, 1))).astype(np.float64)
+        scene_area = ext[0] * ext[1] + ext[1] * ext[2] + ext[2] * ext[0]
+        big = _box_area(tris) * 8.0 >= scene_area
+        assert np.flatnonzero(big).tolist() == h.tolist()
+        _check_tree(sc.bvh(0), tris, h)
+        want = oracle.render_desc(desc)
+        for mode in (api.TRAVERSAL_PER_LANE, api.TRAVERSAL_PACKET):
+            api.set_traversal(mode)
+            try:
+                got = sc.render(desc.cam_pos, api.camera_trans(desc.cam_rot), desc.width, desc.height, desc.depth)
+            finally:
+                api.set_traversal(api.TRAVERSAL_AUTO)
+            assert np.array_equal(_bits(got), _bits(want))
+        # rays that graze walls and spheres at equal t keep the lowest index
+        rays = np.array([[0, 0, 0, 0, -1, 0, -1], [0, 0, 0, 1, 0, 0, -1], [0, 0, 0, 0, 1, 0, 3]], np.float32)
+        sc.commit(0, api.ACCEL_BRUTE)
+        ref = sc.cast_rays(rays)
+        sc.commit(0, api.ACCEL_LBVH)
+        assert np.array_equal(_bits(sc.cast_rays(rays)), _bits(ref))
+
+
+def test_hoisting_limits():
+    """Nothing is hoisted from a scene made of large triangles (more than 32 qualify) or from a
+    small one where they would be more than a quarter; an all-walls scene still builds."""
+    with api.Scene.from_desc(scenes.stock(8, 8)) as sc:
+        sc.commit(0, api.ACCEL_LBVH)
+        assert sc.hoisted(0).size == 0                              # 12 of 24 triangles qualify: too large a share
+    rng = np.random.default_rng(5)
+    with api.Scene() as sc:
+        for _ in range(200):
+            p = rng.uniform(-5, 5, (3, 3))
+            sc.Triangle(p[0], p[1], p[2], (9, 9, 9), 0)
+        sc.addLight((0, 8, 0), 4096)
+        sc.commit(0, api.ACCEL_LBVH)
+        assert sc.hoisted(0).size == 0
+        _check_tree(sc.bvh(0), sc.triangles())
 
 
 def test_duplicate_centroids_still_build():
@@ -73,7 +131,7 @@ def test_duplicate_centroids_still_build():
             sc.Triangle((0, 0, 0), (1, 0, 0), (0, 1, 0), (i % 255, 3, 4), 0)     # 300 identical triangles
         sc.addLight((0, 8, 0), 4096)
         sc.commit(0, api.ACCEL_LBVH)
-        depth = _check_tree(sc.bvh(0), sc.triangles())
+        depth = _check_tree(sc.bvh(0), sc.triangles(), sc.hoisted(0))
         assert depth <= 12
         # all hit at the same t: the lowest index must win (Source.cpp:391 strict <)
         out = sc.cast_rays(np.array([[0.2, 0.2, 1, 0, 0, -1, -1], [0.2, 0.2, 1, 0, 0, -1, 0], [0.2, 0.2, 1, 0, 0, -1, 5]], np.float32))
