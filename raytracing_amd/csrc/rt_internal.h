@@ -90,6 +90,12 @@ struct FrameParams {
 	float m[RT_MAX_FRAMES][16];     // trans, column-major        Source.cpp:1145-1147
 	int n_frames;
 	unsigned int blocks_per_frame;  // set by the launcher
+	// XCD-aware order of the workgroups of a multi-frame LBVH launch (0: off): the frame is cut into
+	// 8 bands of band_blocks workgroups; workgroup b runs on XCD b % 8 (round-robin dispatch) and
+	// renders, as the j-th workgroup of that XCD, band (xcd + frame) % 8 of frame j / band_blocks —
+	// each XCD's L2 then sees the part of the scene behind one band at a time, and the rotation with
+	// the frame number evens out bands of different cost over the frames of the launch.
+	unsigned int band_blocks;
 	long long frame_stride;         // floats between consecutive frames in `out`
 	int width, height;      // Source.cpp:887-888
 	int max_bounces;        // Source.cpp:567

@@ -639,8 +639,17 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 	extern __shared__ float4 s_tri[];
 	const int lds_stride = lds_stride_of(sc.n_tris);
 	float* s_num0 = (float*)s_tri;
-	const int frame = fp.n_frames > 1 ? (int)(blockIdx.x / fp.blocks_per_frame) : 0;      // workgroup-uniform
-	const unsigned int block_in_frame = blockIdx.x - (unsigned int)frame * fp.blocks_per_frame;
+	int frame = fp.n_frames > 1 ? (int)(blockIdx.x / fp.blocks_per_frame) : 0;      // workgroup-uniform
+	unsigned int block_in_frame = blockIdx.x - (unsigned int)frame * fp.blocks_per_frame;
+	if constexpr (ACCEL == 2 || ACCEL == 3) {
+		if (fp.band_blocks > 0) {          // XCD-aware order (rt_internal.h FrameParams::band_blocks)
+			const unsigned int xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+			frame = (int)(j / fp.band_blocks);
+			const unsigned int band = (xcd + (unsigned int)frame) & 7u;
+			block_in_frame = band * fp.band_blocks + (j - (unsigned int)frame * fp.band_blocks);
+			if (block_in_frame >= fp.blocks_per_frame) return;       // (the last band is padded; no barrier in these kernels)
+		}
+	}
 	const vec3 cam = make3(fp.cam[frame][0], fp.cam[frame][1], fp.cam[frame][2]);
 	if constexpr (ACCEL == 0) {
 		// numerator of Source.cpp:383 for rays that start at the camera: the one per-workgroup table
@@ -941,7 +950,22 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 	// 1.27x; 1600: 2.3, 1.4x; 2400: 1.5, 1.6x; 3840x2160: 1.3, 1.7x) and lose above (400x400: 9.2, 0.6x).
 	DevScene sc_sel = sc;
 	if (accel == RT_ACCEL_LBVH && !use_packets(sc, fp.m[0], fp.width, fp.height)) sc_sel.skip_count = 0;
-	const dim3 grid((unsigned)(blocks * n_frames)), block((unsigned)threads);
+	dim3 grid((unsigned)(blocks * n_frames)), block((unsigned)threads);
+	// XCD-aware workgroup order for multi-frame LBVH launches (rt_internal.h FrameParams::band_blocks).
+	// Measured on the 100k-triangle scene, 32 frames per launch, us/frame without | with: 800x800 76 | 72
+	// (L2 misses per wavefront 39 -> 28), 1000x1000 101 | 91, 1600x1600 168 | 161, 2400x2400 305 | 287;
+	// wide and very large frames do not gain (3200x1800 295 | 294, 3840x2160 387 | 397, 7680x4320 1364 | 1365:
+	// a band of full-width rows already spans most of the scene), hence the size limit.
+	fp.band_blocks = 0;
+	static const int env_bands = [] { const char* e = getenv("RT355_XCD_BANDS"); return e ? atoi(e) : -1; }();   // experiments: 0 off, 1 always
+	const bool bands = env_bands >= 0 ? env_bands != 0 : blocks <= 24000;
+	if (accel == RT_ACCEL_LBVH && !count && n_frames >= 8 && bands) {
+		const long long band_blocks = (blocks + 7) / 8;
+		if (band_blocks * 8 * n_frames <= 0x7fffffffLL) {
+			fp.band_blocks = (unsigned int)band_blocks;
+			grid = dim3((unsigned)(band_blocks * 8 * n_frames));
+		}
+	}
 	if (accel == RT_ACCEL_LBVH) {
 		const size_t lds = (size_t)RT_STACK_LDS * RT_STACK_PITCH * sizeof(int);   // [entry][lane]
 		if (count) hipLaunchKernelGGL((render_kernel<2, true>), grid, block, lds, stream, sc_sel, fp, tpw);

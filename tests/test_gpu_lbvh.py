@@ -107,6 +107,35 @@ def test_scene_spanning_triangles_are_hoisted(oracle):
         assert np.array_equal(_bits(sc.cast_rays(rays)), _bits(ref))
 
 
+def test_frame_batches_through_the_tree_equal_single_frames():
+    """Launches of 8 or more frames of an LBVH scene run their workgroups in the XCD-aware band order
+    (rt_kernels.hip launch_render): every frame of the batch must still be the frame rt_render gives
+    for its pose, with both traversals, for frame sizes whose last band is padded."""
+    import torch
+    for (w, h) in ((120, 88), (67, 45)):
+        desc = scenes.spheres(3, 2, w, h, depth=2)
+        poses = scenes.camera_sweep(19, desc.cam_pos, desc.cam_rot)
+        cams = np.array([p for p, _ in poses], np.float32)
+        trs = np.stack([api.camera_trans(r) for _, r in poses])
+        n = w * h * 3
+        with api.Scene.from_desc(desc) as sc:
+            sc.commit(0, api.ACCEL_LBVH)
+            for mode in (api.TRAVERSAL_PER_LANE, api.TRAVERSAL_PACKET):
+                api.set_traversal(mode)
+                try:
+                    singles = [sc.render(cams[i], trs[i], w, h, desc.depth) for i in range(19)]
+                    buf = torch.full((19 * n,), -1.0, dtype=torch.float32, device="cuda:0")
+                    sc.render_frames_device(0, cams, trs, w, h, desc.depth, api.STRICT, buf.data_ptr(), n,
+                                            torch.cuda.current_stream().cuda_stream)
+                    torch.cuda.synchronize()
+                finally:
+                    api.set_traversal(api.TRAVERSAL_AUTO)
+                got = buf.cpu().numpy().reshape(19, h, w, 3)
+                for i in range(19):
+                    assert np.array_equal(_bits(got[i]), _bits(singles[i])), (w, h, mode, i)
+        assert not np.array_equal(singles[0], singles[18])
+
+
 def test_hoisting_limits():
     """Nothing is hoisted from a scene made of large triangles (more than 32 qualify) or from a
     small one where they would be more than a quarter; an all-walls scene still builds."""
