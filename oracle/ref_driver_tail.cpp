@@ -32,6 +32,10 @@
 //        frame (Source.cpp:1307-1308).
 //        out.f32: per frame 33 floats = position, rotations, direction, right, up, moveSpeed,
 //        rotSpeed after the update, and the `trans` the NEXT frame is drawn with (Source.cpp:1145-1147)
+//   ref_render rto <scene.txt> <model.rto> <out_prefix>
+//        as `render`, but after the scene file's own lines the reference's OWN loadModel
+//        (Source.cpp:631-657) appends the records of <model.rto> (e.g. the reference's sample
+//        RayTracing/src/cube.rto) to `triangles`; same three output files.
 //
 // When built with -DORACLE_DEPTH_PARAM the Makefile's sed additionally rewrites the literal
 // `int maxBounces = 1;` (Source.cpp:567) to read g_oracle_max_bounces, set by a `depth` line of
@@ -132,9 +136,15 @@ static void loadVisible() {
 	for (Triangle& t : triangles) visibleTriangles.push_back(t);
 }
 
-static int doRender(const char* scenePath, const char* prefix, int repeat) {
+static int doRender(const char* scenePath, const char* prefix, int repeat, const char* rtoPath = NULL) {
 	Scene sc;
 	if (!parseScene(scenePath, sc)) return 2;
+	if (rtoPath) {
+		FILE* probe = fopen(rtoPath, "rb");       // loadModel calls exit(1) on a missing file (Source.cpp:634-637)
+		if (!probe) { fprintf(stderr, "ref_render: cannot open %s\n", rtoPath); return 2; }
+		fclose(probe);
+		loadModel(rtoPath);                       // Source.cpp:631
+	}
 #ifndef ORACLE_DEPTH_PARAM
 	if (sc.depth != 1) { fprintf(stderr, "ref_render: this build keeps the reference's literal maxBounces = 1\n"); return 3; }
 #endif
@@ -236,12 +246,15 @@ int main(int argc, char** argv) {
 		int repeat = argc >= 5 ? atoi(argv[4]) : 1;
 		return oracle_driver::doRender(argv[2], argv[3], repeat < 1 ? 1 : repeat);
 	}
+	if (argc >= 5 && !strcmp(argv[1], "rto")) {
+		return oracle_driver::doRender(argv[2], argv[4], 1, argv[3]);
+	}
 	if (argc >= 5 && !strcmp(argv[1], "rays")) {
 		return oracle_driver::doRays(argv[2], argv[3], argv[4]);
 	}
 	if (argc >= 4 && !strcmp(argv[1], "camera")) {
 		return oracle_driver::doCamera(argv[2], argv[3]);
 	}
-	fprintf(stderr, "usage: ref_render render <scene.txt> <out_prefix> [repeat]\n       ref_render rays <scene.txt> <rays.f32> <out.f32>\n");
+	fprintf(stderr, "usage: ref_render render <scene.txt> <out_prefix> [repeat]\n       ref_render rays <scene.txt> <rays.f32> <out.f32>\n       ref_render rto <scene.txt> <model.rto> <out_prefix>\n");
 	return 1;
 }

@@ -17,7 +17,7 @@ def pytest_configure(config):
 
 
 def golden_cases():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and not f.startswith(("rays_", "camera_")))
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and not f.startswith(("rays_", "camera_", "rto_")))
 
 
 def load_golden(name):
@@ -29,6 +29,19 @@ def load_golden(name):
                 sha256=bytes(z["sha256"]).hex(),
                 frame=z["frame"] if "frame" in z.files else None,
                 q8=z["q8"] if "q8" in z.files else None)
+
+
+def rto_cases():
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.startswith("rto_") and f.endswith(".npz"))
+
+
+def load_rto_golden(name):
+    """Fixtures of the reference's own loadModel (Source.cpp:631-657; make_golden.py rto_cases):
+    -> dict(desc = the scene WITHOUT the model, rto = bytes of the model file, tris, trans, frame, sha256)"""
+    from raytracing_amd import scenes
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    return dict(desc=scenes.SceneDesc.from_text(bytes(z["scene"]).decode(), name), rto=bytes(z["rto"]), tris=z["tris"],
+                trans=z["trans"], frame=z["frame"], sha256=bytes(z["sha256"]).hex())
 
 
 @pytest.fixture(scope="session")

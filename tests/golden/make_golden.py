@@ -18,6 +18,11 @@ scene files written from raytracing_amd/scenes.py, and (3) stores what they prod
   rays_<case>.npz   scene, rays (K,7), out (K,6): the reference's castRay on K hand-made and
                random rays (out = didHit, index, distance, point).
 
+  rto_<case>.npz    scene (text, without the model), rto (the bytes of a .rto model file), tris, trans,
+               frame, sha256: the reference's own loadModel (Source.cpp:631-657) appending the model to
+               the scene, rendered by its getPixelData.  rto_cube_* holds the reference's sample data
+               file RayTracing/src/cube.rto (2 records, no blanks after the commas).
+
 Fixtures are data (inputs + expected outputs); no reference source text is stored.
 Usage:  python tests/golden/make_golden.py
 """
@@ -189,9 +194,61 @@ def camera_case(tmp, index):
     print("camera_path: %d frames, %d at the pitch clamp" % (len(ms), index["camera_path"]["clamped_frames"]))
 
 
+RTO_SPACED = b"""(0, 3, 0), (0, 0, 0), (2, 2, 2), (250, 120, 10);
+(0, 3, 0), (0, 0, 180), (2, 2, 2), (250, 120, 10);
+(-4.5, -2.25, 1), (30, -60, 15.5), (1.5, 3, 1), (12, 200, 99);
+
+(3, 1, -2), (-90, 0, 45), (0.5, 0.5, 0.5), (255, 255, 255);  (3, 2, -2), (-90, 0, 225), (.5, .5, .5), (1, 2, 3);
+"""
+
+
+def rto_cases(tmp, index):
+    """loadModel (Source.cpp:631-657): the reference's sample cube.rto alone under a light and inside the
+    room, and a hand-written model in the spaced form the format string shows (blank line, two records
+    on one line, a leading-dot number)."""
+    sample = open("/root/reference/RayTracing/src/cube.rto", "rb").read()
+    alone = scenes.SceneDesc("rto_cube", width=96, height=96).light((0, 8, 0), 4096)
+    inside = scenes.room(128, 128)
+    inside.name = "rto_room_cube"
+    spaced = scenes.stock(80, 60)
+    spaced.name = "rto_stock_spaced"
+    for name, sc, model in (("rto_cube_96", alone, sample), ("rto_room_cube_128", inside, sample),
+                            ("rto_stock_spaced_80x60", spaced, RTO_SPACED)):
+        scene_path, model_path, prefix = os.path.join(tmp, "s.txt"), os.path.join(tmp, "m.rto"), os.path.join(tmp, name)
+        text = sc.to_text()
+        with open(scene_path, "w") as f:
+            f.write(text)
+        with open(model_path, "wb") as f:
+            f.write(model)
+        res = subprocess.run([os.path.join(REF, "ref_render"), "rto", scene_path, model_path, prefix],
+                             capture_output=True, text=True, check=True)
+        info = json.loads(res.stdout)
+        tris = np.fromfile(prefix + ".tris.f32", dtype=np.float32).reshape(-1, 28)
+        trans = np.fromfile(prefix + ".trans.f32", dtype=np.float32)
+        frame = np.fromfile(prefix + ".frame.f32", dtype=np.float32).reshape(sc.height, sc.width, 3)
+        assert tris.shape[0] == info["triangles"] > sc.n_triangles
+        digest = hashlib.sha256(frame.tobytes()).digest()
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, scene=np.frombuffer(text.encode(), dtype=np.uint8), rto=np.frombuffer(model, dtype=np.uint8),
+                            tris=tris, trans=trans, frame=frame, sha256=np.frombuffer(digest, dtype=np.uint8))
+        index[name] = dict(triangles=int(info["triangles"]), from_model=int(info["triangles"]) - sc.n_triangles, width=sc.width,
+                           height=sc.height, sha256=digest.hex(), bytes=os.path.getsize(path),
+                           nonzero_pixels=int((frame.sum(axis=2) != 0).sum()))
+        print("%-24s N=%-3d (%d from the model) %dx%d  %d lit pixels" % (name, info["triangles"], index[name]["from_model"],
+                                                                       sc.width, sc.height, index[name]["nonzero_pixels"]))
+
+
 def main():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
     rng = np.random.default_rng(20251110)
+    if "--rto-only" in sys.argv:
+        index = json.load(open(os.path.join(HERE, "INDEX.json")))
+        with tempfile.TemporaryDirectory() as tmp:
+            rto_cases(tmp, index)
+        with open(os.path.join(HERE, "INDEX.json"), "w") as f:
+            json.dump(index, f, indent=1, sort_keys=True)
+            f.write("\n")
+        return
     if "--camera-only" in sys.argv:
         index = json.load(open(os.path.join(HERE, "INDEX.json")))
         with tempfile.TemporaryDirectory() as tmp:
@@ -203,6 +260,7 @@ def main():
     index = {}
     with tempfile.TemporaryDirectory() as tmp:
         camera_case(tmp, index)
+        rto_cases(tmp, index)
         for name, sc in cases():
             text, tris, trans, frame, info = run_ref(sc, tmp)
             digest = hashlib.sha256(frame.tobytes()).digest()

@@ -8,7 +8,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import ROOT, golden_cases, load_golden
+from conftest import ROOT, golden_cases, load_golden, load_rto_golden, rto_cases
 from raytracing_amd import api, scenes
 
 
@@ -100,6 +100,23 @@ def test_rto_loader(tmp_path):
         with pytest.raises(api.RtError) as e:
             a.loadModel(str(bad))
         assert e.value.code == -5
+
+
+@pytest.mark.parametrize("case", rto_cases())
+def test_rto_loader_equals_reference_loadModel(case, tmp_path):
+    """rt_scene_load_rto against the reference's OWN loadModel (Source.cpp:631-657) run on the same
+    bytes — among them the reference's sample RayTracing/src/cube.rto, written without blanks after
+    the commas: the appended Triangle records are the reference's, bit for bit."""
+    g = load_rto_golden(case)
+    f = tmp_path / "model.rto"
+    f.write_bytes(g["rto"])
+    with api.Scene.from_desc(g["desc"]) as sc:
+        before = sc.n_triangles
+        added = sc.loadModel(str(f))
+        assert added == g["tris"].shape[0] - before > 0
+        got = sc.triangles()
+    assert np.array_equal(_bits(got), _bits(g["tris"]))
+    assert np.all(got[before:, 27] == 0)                      # loadModel always passes shininess 0 (Source.cpp:653)
 
 
 def test_quantize_matches_oracle(oracle):

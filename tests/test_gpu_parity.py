@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, golden_cases, load_golden
+from conftest import GOLDEN, golden_cases, load_golden, load_rto_golden, rto_cases
 from raytracing_amd import api, scenes
 
 pytestmark = pytest.mark.gpu
@@ -34,6 +34,26 @@ def test_golden_frames_bit_exact(case):
         assert np.array_equal(_bits(frame), _bits(g["frame"]))
     if g["q8"] is not None:
         assert np.array_equal(api.quantize(frame), g["q8"])
+
+
+@pytest.mark.parametrize("case", rto_cases())
+def test_loaded_models_render_bit_exact(case, tmp_path):
+    """rt_scene_load_rto -> commit -> render against what the reference's own loadModel
+    (Source.cpp:631-657) + getPixelData produced from the same bytes (its sample cube.rto among them),
+    by brute force and through the LBVH."""
+    g = load_rto_golden(case)
+    d = g["desc"]
+    f = tmp_path / "model.rto"
+    f.write_bytes(g["rto"])
+    with api.Scene.from_desc(d) as sc:
+        assert sc.loadModel(str(f)) == g["tris"].shape[0] - d.n_triangles
+        assert np.array_equal(_bits(sc.triangles()), _bits(g["tris"]))
+        for accel in (api.ACCEL_BRUTE, api.ACCEL_LBVH):
+            sc.commit(0, accel)
+            frame = sc.render(d.cam_pos, g["trans"], d.width, d.height, d.depth)
+            assert np.array_equal(_bits(frame), _bits(g["frame"])), accel
+            assert hashlib.sha256(frame.tobytes()).hexdigest() == g["sha256"]
+    assert (g["frame"].max(axis=2) > 0).sum() >= 40
 
 
 def test_cast_rays_known_answers():

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, golden_cases, load_golden
+from conftest import GOLDEN, golden_cases, load_golden, load_rto_golden, rto_cases
 
 
 def _bits(a):
@@ -35,6 +35,19 @@ def test_render_bit_exact(oracle, case):
         assert np.array_equal(_bits(frame), _bits(g["frame"]))
     if g["q8"] is not None:
         assert np.array_equal(oracle.quantize(frame), g["q8"])
+
+
+@pytest.mark.parametrize("case", rto_cases())
+def test_render_of_loaded_models_bit_exact(oracle, case):
+    """Frames the reference rendered after its own loadModel (Source.cpp:631-657) appended a .rto model:
+    the restatement renders the fixture's Triangle records to the same bits."""
+    g = load_rto_golden(case)
+    d = g["desc"]
+    _, lights = oracle.build_scene(d)
+    assert np.array_equal(_bits(oracle.camera_trans(d.cam_rot)), _bits(g["trans"]))
+    frame = oracle.render(g["tris"], lights, d.cam_pos, g["trans"], d.width, d.height, d.depth)
+    assert np.array_equal(_bits(frame), _bits(g["frame"]))
+    assert hashlib.sha256(frame.tobytes()).hexdigest() == g["sha256"]
 
 
 def test_render_threaded_equals_serial(oracle):
