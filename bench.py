@@ -5,25 +5,31 @@ per-pixel render loop at 800x800 on 1..8 MI355X (BASELINE.json `metric`).
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A *step* is one frame: one pass of the render loop (rt_render_device, include/rt355.h) over the
-BASELINE config-2 workload — the README-style room (26 triangles, two mirror walls, blue occluder,
-one light), 800x800, reference depth 1 — into a framebuffer that stays resident in HBM.  The scene
-is already committed (resident) when the timed region starts.  Successive frames walk the
-deterministic 64-pose camera path of config 5 (scenes.camera_sweep); with N ranks the frames are
-dealt round-robin to the ranks (frames are independent units: no data-path collective, weak
-scaling — every rank renders K frames).  `value` = rays of all frames of all ranks / wall time of
-the slowest rank.
-
-Rank 0 prints ONE JSON line.  Besides the contract keys it carries
+One GPU (the default): the workload is BASELINE config 2 — the README-style room (26 triangles, two
+mirror walls, blue occluder, one light), 800x800, reference depth 1.  A *step* is ONE LAUNCH of the
+render loop over a batch of 32 consecutive frames of the deterministic camera path of config 5
+(rt_render_frames_device, include/rt355.h; the poses come from the reference's own controller,
+api.camera_sweep -> rt_camera_path), into framebuffers that stay resident in HBM; the scene is
+committed before the timed region starts.  K steps = 32*K frames.  `value` = rays of all frames /
+wall time.  The line also carries, measured outside the timed region of the headline:
+  configs       the other BASELINE configs on this GPU (stock 800x800, facing mirrors 3840x2160 depth
+                16, 102 412 triangles through the LBVH at 800x800 and 3840x2160 with the build time,
+                the room at 7680x4320), each with ms/frame, Mrays/s, kernel ms and roofline fraction
+  hand_off      one frame per launch and the end-to-end cost of the viewer hand-off (Source.cpp:1270):
+                rt_render into pageable memory, and rt_render_async into pinned double buffers
   roofline      FP32 VALU roofline of the render kernel: algorithmic FLOPs (SURVEY §8d pricing,
-                counted by rt_render_stats on the same frames) / mean kernel duration from HIP
-                events on the launch stream / 157.3 TFLOP/s
+                counted by rt_render_stats in the same traversal on the same poses) / mean kernel
+                duration from HIP events on the launch stream / 157.3 TFLOP/s
   cpu_baseline  the reference's own getPixelData loop (oracle/_ref/ref_render, built from
                 /root/reference in the build container) or, when that binary is absent, the C
-                restatement in oracle/ — one host thread, same scene and size, a bounded number
-                of frames.
-Other workloads (BASELINE configs 3-5) are selected with --workload; they are not what the driver
-runs.
+                restatement in oracle/ — one host thread, same scene and size, a bounded sample.
+
+Several GPUs (--gpus N > 1, one rank per GPU): the default workload is BASELINE config 5, the one
+north_star partitions — 7680x4320 frames of the same camera path, each split into interleaved
+16-row tiles (tile t -> rank t mod N, rt_render_tiles_device), one exchange step per frame that
+gathers the shards on rank 0 over RCCL (sharding.TileExchange, pipelined over two shard buffers).  A
+step is one frame; total work is fixed ("scaling": "strong").  `--workload room800 --gpus N` keeps the
+frame-parallel mode instead (rank r renders batches r, r+N, ...; no collective; weak scaling).
 """
 from __future__ import annotations
 
@@ -41,44 +47,38 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_VALU_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+N_POSES = 64
+
+# name -> (scene builder, acceleration, label, frames per launch)
+WORKLOADS = {
+    "room800": (lambda s: s.room(800, 800), "brute",
+                "README room scene (26 triangles, 2 mirror walls, occluder, 1 light) 800x800 depth 1", 32),
+    "stock800": (lambda s: s.stock(800, 800), "brute", "unmodified v1 scene (24 triangles, 1 light) 800x800 depth 1", 32),
+    "mirrors4k": (lambda s: s.mirrors(3840, 2160, 16), "brute", "facing mirrors 3840x2160 depth 16", 32),
+    "spheres800": (lambda s: s.spheres(20, 4, 800, 800), "lbvh", "20 icospheres x 5120 + room = 102412 triangles, 800x800, LBVH", 32),
+    "spheres4k": (lambda s: s.spheres(20, 4, 3840, 2160), "lbvh", "102412 triangles, 3840x2160, LBVH", 32),
+    "sweep8k": (lambda s: s.room(7680, 4320), "brute", "README room scene 7680x4320, 64-pose camera path", 8),
+    "sweep8k_spheres": (lambda s: s.spheres(20, 4, 7680, 4320), "lbvh", "102412 triangles 7680x4320, 64-pose camera path, LBVH", 8),
+}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=512)
-    ap.add_argument("--warmup", type=int, default=32)
-    ap.add_argument("--workload", default="room800",
-                    choices=["room800", "stock800", "mirrors4k", "spheres800", "spheres4k", "sweep8k", "sweep8k_spheres"])
-    ap.add_argument("--mode", default="strict", choices=["strict", "fast"])
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: room800 on one GPU, sweep8k (row tiles + gather) on several")
     ap.add_argument("--tiles-per-wave", type=int, default=0)
-    ap.add_argument("--frames-per-launch", type=int, default=32,
-                    help="frames of the camera path rendered by one launch (rt_render_frames_device); 1 = one launch per frame")
+    ap.add_argument("--frames-per-launch", type=int, default=0, help="frames per launch (= per step); 0: the workload's own (32; 8 at 8K)")
     ap.add_argument("--size", type=int, nargs=2, default=None, help="override the workload's frame size (experiments)")
+    ap.add_argument("--traversal", default="auto", choices=["auto", "per-lane", "packet"])
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo lets several ranks share one GPU to rehearse the N>1 path")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other configs and the hand-off numbers")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
-
-
-def make_workload(name):
-    from raytracing_amd import scenes
-    if name == "room800":
-        return scenes.room(800, 800), "brute", "README room scene (26 triangles, 2 mirror walls, occluder, 1 light) 800x800 depth 1"
-    if name == "stock800":
-        return scenes.stock(800, 800), "brute", "unmodified v1 scene (24 triangles, 1 light) 800x800 depth 1"
-    if name == "mirrors4k":
-        return scenes.mirrors(3840, 2160, 16), "brute", "facing mirrors 3840x2160 depth 16"
-    if name == "spheres800":
-        return scenes.spheres(20, 4, 800, 800), "lbvh", "20 icospheres x 5120 + room = 102412 triangles, 800x800, LBVH"
-    if name == "spheres4k":
-        return scenes.spheres(20, 4, 3840, 2160), "lbvh", "102412 triangles, 3840x2160, LBVH"
-    if name == "sweep8k":
-        return scenes.room(7680, 4320), "brute", "README room scene 7680x4320, 64-pose sweep, interleaved row tiles + gather"
-    if name == "sweep8k_spheres":
-        return scenes.spheres(20, 4, 7680, 4320), "lbvh", "102412 triangles 7680x4320, 64-pose sweep, LBVH, interleaved row tiles + gather"
-    raise ValueError(name)
 
 
 def cpu_baseline(desc, seconds):
@@ -132,6 +132,336 @@ def cpu_threaded(desc, threads):
     return best
 
 
+class Workload:
+    """One committed scene + its camera path + pre-marshalled launch arguments."""
+
+    def __init__(self, api, torch, name, dev, args, frames_per_launch=0):
+        from raytracing_amd import scenes
+        import ctypes as C
+        build, accel_name, label, fpl = WORKLOADS[name]
+        self.api, self.torch, self.C, self.name, self.dev = api, torch, C, name, dev
+        desc = build(scenes)
+        if args.size:
+            desc = desc.with_size(args.size[0], args.size[1])
+            label += " [size overridden to %dx%d]" % tuple(args.size)
+        self.desc, self.accel_name, self.label = desc, accel_name, label
+        self.fpl = max(1, min(32, frames_per_launch or args.frames_per_launch or fpl))
+        self.W, self.H, self.D = desc.width, desc.height, desc.depth
+        self.scene = api.Scene.from_desc(desc)
+        self.scene.set_traversal({"auto": api.TRAVERSAL_AUTO, "per-lane": api.TRAVERSAL_PER_LANE, "packet": api.TRAVERSAL_PACKET}[args.traversal])
+        if args.tiles_per_wave:
+            self.scene.set_tiles_per_wave(args.tiles_per_wave)
+        self.scene.commit(dev, api.ACCEL_LBVH if accel_name == "lbvh" else api.ACCEL_BRUTE)
+        self.cams, self.trans = api.camera_sweep(N_POSES, desc.cam_pos, desc.cam_rot)     # (64,3), (64,16): rt_camera_path
+        self.rays_of, self.flops_of = {}, {}
+        self.fb = None
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self._batches = {}
+
+    def count(self, frames):
+        """Rays and algorithmic FLOPs per pose, counted by the instrumented kernel in the traversal the
+        frame really gets (outside every timed region; brute force: identical to the oracle's counters)."""
+        for f in sorted(set(frames)):
+            if f not in self.rays_of:
+                _, st = self.scene.render_stats(self.cams[f], self.trans[f], self.W, self.H, self.D, want_frame=False)
+                self.rays_of[f], self.flops_of[f] = st.rays, st.flops
+
+    def launch(self, frames):
+        """One launch for up to 32 frames of the path; the frames stay resident in HBM."""
+        api, C = self.api, self.C
+        if self.fb is None:
+            self.fb = self.torch.empty(self.fpl * self.H * self.W * 3, dtype=self.torch.float32, device="cuda")
+        _, _, cp, tp = self.prepare(frames)
+        rc = api.lib().rt_render_frames_device(self.scene._h, self.dev, len(frames), cp, tp, self.W, self.H, self.D, api.STRICT,
+                                               C.c_void_p(self.fb.data_ptr()), C.c_size_t(self.H * self.W * 3), C.c_void_p(self.stream))
+        if rc != 0:
+            raise api.RtError(rc, api.lib().rt_last_error().decode())
+
+    def prepare(self, frames):
+        """Marshalled pose arrays of one batch (built once, ahead of the timed loop)."""
+        key = tuple(frames)
+        if key not in self._batches:
+            fptr = self.C.POINTER(self.C.c_float)
+            cams = np.ascontiguousarray(self.cams[list(frames)], dtype=np.float32)
+            trs = np.ascontiguousarray(self.trans[list(frames)], dtype=np.float32)
+            self._batches[key] = (cams, trs, cams.ctypes.data_as(fptr), trs.ctypes.data_as(fptr))
+        return self._batches[key]
+
+    def batch(self, step, world=1, rank=0):
+        """Poses of step `step` of rank `rank`: consecutive frames of the 64-pose path."""
+        first = ((step * world + rank) * self.fpl) % N_POSES
+        return [(first + k) % N_POSES for k in range(self.fpl)]
+
+    def traversal(self):
+        return {0: None, 1: "per-lane", 2: "packet"}[self.scene.traversal(self.dev, self.trans[0], self.W, self.H)]
+
+    def timed_launches(self, batches):
+        """-> (wall seconds, mean kernel ms per launch from HIP events on the launch stream)."""
+        torch = self.torch
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev0.record()
+        for b in batches:
+            self.launch(b)
+        ev1.record()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, ev0.elapsed_time(ev1) / max(1, len(batches))
+
+    def close(self):
+        self.fb = None
+        self.scene.close()
+
+
+def roofline_of(flops_per_launch, kernel_ms, fpl, launches, workload):
+    achieved = flops_per_launch / (kernel_ms * 1e-3) / 1e12
+    pmc = read_profile_json("traffic.json").get(workload)
+    issued = read_profile_json("issued.json").get(workload)
+    return {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": pmc, "issued_tflops": issued,
+            "kernel_ms": kernel_ms, "flops_per_launch": flops_per_launch, "frames_per_launch": fpl, "launches": launches,
+            "note": "FP32 VALU roofline (SURVEY 8d): nothing here is HBM- or MFMA-shaped; algorithmic FLOPs = 14/plane + 6/point + "
+                    "17/edge term + 22/box + 32|29|30 per ray, counted in the traversal that is timed; issued_tflops = VALU FLOPs "
+                    "the kernel really executes per second (PMC pass under profiles/), secondary"}
+
+
+def side_config(api, torch, name, dev, args, launches=3):
+    """One of the other BASELINE configs, measured on its own: `launches` timed launches after one warm-up."""
+    w = Workload(api, torch, name, dev, args)
+    try:
+        batches = [w.batch(s) for s in range(launches)]
+        w.count([f for b in batches for f in b])
+        w.launch(batches[0])
+        wall, kernel_ms = w.timed_launches(batches)
+        frames = launches * w.fpl
+        rays = float(sum(w.rays_of[f] for b in batches for f in b))
+        flops = float(sum(w.flops_of[f] for b in batches for f in b))
+        out = {"workload": name, "label": w.label, "accel": w.accel_name, "traversal": w.traversal(), "width": w.W, "height": w.H,
+               "max_bounces": w.D, "triangles": w.scene.n_triangles, "frames_per_launch": w.fpl, "launches": launches,
+               "ms_per_frame": wall / frames * 1e3, "Mrays_per_s": rays / wall / 1e6, "rays_per_frame": rays / frames,
+               "kernel_ms": kernel_ms, "kernel_ms_per_frame": kernel_ms / w.fpl,
+               "roofline_frac": flops / launches / (kernel_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
+               "flops_per_ray": flops / rays}
+        if w.accel_name == "lbvh":
+            out["build_ms"] = w.scene.build_ms(dev)
+            out["bvh_depth"] = list(w.scene.bvh_depth(dev))
+        return out
+    finally:
+        w.close()
+        torch.cuda.empty_cache()
+
+
+def hand_off(api, torch, w):
+    """What one frame costs a viewer that wants it in host memory (Source.cpp:1270 uploads `data` every
+    frame): a lone launch, rt_render into pageable memory, rt_render_async into two pinned buffers."""
+    sc, W, H, D = w.scene, w.W, w.H, w.D
+    n = 40
+    buf = torch.empty(H * W * 3, dtype=torch.float32, device="cuda")
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for timed in (False, True):
+        if timed:
+            torch.cuda.synchronize()
+            ev0.record()
+        for i in range(n):
+            sc.render_device(w.dev, w.cams[i % N_POSES], w.trans[i % N_POSES], W, H, D, api.STRICT, buf.data_ptr(), w.stream)
+        if timed:
+            ev1.record()
+    torch.cuda.synchronize()
+    single_us = ev0.elapsed_time(ev1) / n * 1e3
+    sc.render(w.cams[0], w.trans[0], W, H, D)
+    t0 = time.perf_counter()
+    for i in range(n):
+        sc.render(w.cams[i % N_POSES], w.trans[i % N_POSES], W, H, D)
+    sync_ms = (time.perf_counter() - t0) / n * 1e3
+    bufs = [api.HostFrame(W, H), api.HostFrame(W, H)]
+    tickets = [sc.render_async(w.cams[0], w.trans[0], W, H, D, bufs[0]), None]
+    sc.render_wait(tickets[0])
+    t0 = time.perf_counter()
+    for i in range(n):
+        tickets[i & 1] = sc.render_async(w.cams[i % N_POSES], w.trans[i % N_POSES], W, H, D, bufs[i & 1])
+        if i > 0:
+            sc.render_wait(tickets[(i - 1) & 1])
+    sc.render_wait(tickets[(n - 1) & 1])
+    async_ms = (time.perf_counter() - t0) / n * 1e3
+    for b in bufs:
+        b.close()
+    mb = H * W * 12 / 1e6
+    return {"single_frame_launch_us": single_us, "end_to_end_ms": sync_ms, "end_to_end_async_ms": async_ms,
+            "frame_MB": mb, "async_GBps": mb / async_ms,
+            "note": "one %dx%d frame per launch (HIP events, %d back-to-back launches); end_to_end_ms = rt_render incl. the D2H copy into "
+                    "pageable memory; end_to_end_async_ms = rt_render_async into two pinned frames, frame f copying while f+1 renders "
+                    "(wall per frame)" % (W, H, n)}
+
+
+def read_profile_json(name):
+    """Per-workload numbers from the PMC passes kept under profiles/ (collected by tools/profile.sh in
+    separate rocprofv3 --pmc runs): traffic.json = HBM bytes per launch, issued.json = issued VALU TFLOP/s."""
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            d = json.load(f)
+            return d if isinstance(d, dict) else {}
+    except (OSError, ValueError):
+        return {}
+
+
+def run_frames_mode(args, api, torch, dist, rank, world, dev, on_gpu, name):
+    w = Workload(api, torch, name, dev, args)
+    fpl = w.fpl
+    mine = [w.batch(s, world, rank) for s in range(args.steps)]
+    w.count([f for b in mine for f in b])
+    for s in range(args.warmup):
+        w.launch(w.batch(s, world, rank))
+    for b in mine:                          # marshal every batch of the timed loop ahead of it
+        w.prepare(b)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for b in mine:
+        w.launch(b)
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps          # HIP events on the launch stream: mean launch duration
+    my_rays = float(sum(w.rays_of[f] for b in mine for f in b))
+    my_flops = float(sum(w.flops_of[f] for b in mine for f in b))
+    total_rays = my_rays
+    if dist:
+        t = torch.tensor([wall], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+        r = torch.tensor([my_rays], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        total_rays = float(r[0].item())
+    out = None
+    if rank == 0:
+        frames_total = args.steps * fpl * world
+        out = {
+            "metric": "Mrays/s (primary+bounce+shadow) at 800x800" if name.endswith("800") else "Mrays/s (primary+bounce+shadow)",
+            "value": total_rays / wall / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3, "frames_per_step": fpl, "ms_per_frame": wall / (args.steps * fpl) * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": w.label, "accel": w.accel_name, "traversal": w.traversal(), "width": w.W, "height": w.H,
+                       "max_bounces": w.D, "triangles": w.scene.n_triangles, "lights": w.scene.n_lights, "frames_per_step": fpl,
+                       "frames": "64-pose camera path (rt_camera_path: look right + forward, 16 ms frames); step s of rank r = one launch "
+                                 "over the %d consecutive poses from ((s*N + r)*%d) mod 64" % (fpl, fpl),
+                       "rays_per_frame_mean": total_rays / frames_total, "parallelism": "frames x%d" % world},
+            "roofline": roofline_of(my_flops / args.steps, kernel_ms, fpl, args.steps, name),
+        }
+        if world == 1 and not args.no_configs:
+            out["hand_off"] = hand_off(api, torch, w)
+    w_desc = w.desc
+    w.close()
+    torch.cuda.empty_cache()
+    if rank == 0 and world == 1:
+        if not args.no_configs:
+            out["configs"] = [side_config(api, torch, n, dev, args) for n in
+                              ("stock800", "mirrors4k", "spheres800", "spheres4k", "sweep8k") if n != name]
+        if not args.no_cpu:
+            cb = cpu_baseline(w_desc, args.cpu_seconds)
+            out["cpu_baseline"] = cb
+            threads = min(16, os.cpu_count() or 1)
+            mt = cpu_threaded(w_desc, threads)
+            out["cpu_threaded"] = {"value": cb["rays_per_frame"] / mt / 1e6, "unit": "Mrays/s",
+                                   "cores": threads, "kind": "port", "ms_per_frame": mt * 1e3,
+                                   "sample": "row-interleaved pthreads over the same frame (stands in for the reference's disabled std::execution::par loop)"}
+            out["gpu_over_cpu_1thread"] = out["value"] / cb["value"]
+    return out
+
+
+def run_tile_mode(args, api, torch, dist, rank, world, dev, on_gpu, name):
+    """BASELINE config 5: every rank renders its interleaved 16-row tiles of the SAME frame, one exchange
+    step per frame gathers them on rank 0 (pipelined: frame f+1 renders while f is in flight)."""
+    from raytracing_amd import sharding
+    w = Workload(api, torch, name, dev, args, frames_per_launch=1)
+    W, H, D, sc = w.W, w.H, w.D, w.scene
+    frames = [s % N_POSES for s in range(args.steps)]
+    w.count(frames)
+    tile_rows = 16
+    rows = api.shard_rows(H, tile_rows, rank, world)
+    ex = sharding.TileExchange(dist, rank, world, H, W, tile_rows,
+                               lambda n: torch.empty(n, dtype=torch.float32, device="cuda" if on_gpu else "cpu"), depth=2)
+    stage = None if on_gpu else torch.empty(rows * W * 3, dtype=torch.float32, device="cuda")   # gloo rehearsal: shards go through host memory
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in frames]
+
+    def run(fs, timed):
+        for i, f in enumerate(fs):
+            buf = ex.shard(i)
+            dst = buf if on_gpu else stage
+            if timed:
+                evs[i][0].record()
+            sc.render_tiles_device(dev, w.cams[f], w.trans[f], W, H, D, api.STRICT, tile_rows, rank, world, dst.data_ptr(), w.stream)
+            if timed:
+                evs[i][1].record()
+            if not on_gpu:
+                buf.copy_(stage)
+            ex.submit(i)
+        ex.drain()
+
+    # the same frames by ONE GPU in one piece (rank 0, outside the timed region): the N=1 point of this workload
+    single = None
+    if rank == 0:
+        whole = torch.empty(H * W * 3, dtype=torch.float32, device="cuda")
+        k = min(8, len(frames))
+        for timed in (False, True):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for f in frames[:k]:
+                sc.render_device(dev, w.cams[f], w.trans[f], W, H, D, api.STRICT, whole.data_ptr(), w.stream)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter() - t0
+        single = {"ms_per_frame": t1 / k * 1e3, "value": sum(w.rays_of[f] for f in frames[:k]) / t1 / 1e6, "frames": k,
+                  "note": "whole frames on rank 0's GPU alone, one frame per launch, frames resident in HBM, no exchange"}
+        del whole
+    run([frames[s % len(frames)] for s in range(args.warmup)], False)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(frames, True)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)          # this rank's shard kernel, HIP events on the launch stream
+    where = "cuda" if on_gpu else "cpu"
+    t = torch.tensor([wall, kernel_ms], dtype=torch.float64, device=where)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall, kernel_ms_max = float(t[0].item()), float(t[1].item())
+    out = None
+    if rank == 0:
+        rays = float(sum(w.rays_of[f] for f in frames))
+        flops = float(sum(w.flops_of[f] for f in frames))
+        share = rows / H
+        out = {
+            "metric": "Mrays/s (primary+bounce+shadow)", "value": rays / wall / 1e6, "unit": "Mrays/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3, "frames_per_step": 1,
+            "ms_per_frame": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": w.label + ", interleaved 16-row tiles + gather to rank 0", "accel": w.accel_name, "traversal": w.traversal(),
+                       "width": W, "height": H, "max_bounces": D, "triangles": sc.n_triangles, "lights": sc.n_lights,
+                       "frames": "64-pose camera path (rt_camera_path), step s = pose s mod 64, every rank renders its tiles of it",
+                       "rays_per_frame_mean": rays / args.steps, "parallelism": "row tiles x%d" % world,
+                       "exchange": "point-to-point sends of the compact fp32 shards to rank 0 (%s), two shard buffers per rank" % args.backend},
+            "roofline": roofline_of(flops / args.steps * share, kernel_ms, 1, args.steps, name),
+            "exchange": {"kernel_ms_rank0": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
+                         "non_render_ms_per_frame": wall / args.steps * 1e3 - kernel_ms_max,
+                         "shard_MB": rows * W * 12 / 1e6,
+                         "note": "roofline is rank 0's shard kernel: the frame's counted FLOPs x its share of the rows (%d of %d, interleaved "
+                                 "tiles); non_render_ms_per_frame = wall per frame minus the slowest rank's kernel = exchange + "
+                                 "de-interleave not hidden behind rendering" % (rows, H)},
+            "single_gpu": single,
+        }
+    w.close()
+    return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -141,7 +471,7 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     import torch
-    from raytracing_amd import api, scenes, sharding
+    from raytracing_amd import api
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the render loop has no CPU path")
@@ -156,178 +486,17 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    desc, accel_name, label = make_workload(args.workload)
-    if args.size:
-        desc = desc.with_size(args.size[0], args.size[1])
-        label += " [size overridden to %dx%d]" % tuple(args.size)
-    accel = api.ACCEL_LBVH if accel_name == "lbvh" else api.ACCEL_BRUTE
-    mode = api.FAST if args.mode == "fast" else api.STRICT
-    if args.tiles_per_wave:
-        api.lib().rt_set_tiles_per_wave(args.tiles_per_wave)
-
-    scene = api.Scene.from_desc(desc)
-    scene.commit(dev, accel)
-    W, H, D = desc.width, desc.height, desc.depth
-    poses = scenes.camera_sweep(64, desc.cam_pos, desc.cam_rot)
-    trans = [api.camera_trans(r) for _, r in poses]
-
-    # work per pose (rays and algorithmic FLOPs), counted by the instrumented kernel outside the
-    # timed region; identical to the oracle's counters (tests/test_gpu_parity.py)
-    tile_mode = args.workload.startswith("sweep8k") and world > 1
+    name = args.workload or ("room800" if world == 1 else "sweep8k")
+    tile_mode = world > 1 and name.startswith("sweep8k")
     if tile_mode:
-        my_frames = [s % 64 for s in range(args.steps)]         # every rank works on the same frame
+        out = run_tile_mode(args, api, torch, dist, rank, world, dev, on_gpu, name)
     else:
-        my_frames = sharding.frames_for_rank(args.steps, world, rank)
-    need = sorted(set(my_frames))
-    rays_of, flops_of = {}, {}
-    for f in need:
-        _, st = scene.render_stats(poses[f][0], trans[f], W, H, D, want_frame=False)
-        rays_of[f], flops_of[f] = st.rays, st.flops
-
-    if tile_mode:
-        tile_rows = 16
-        rows = api.shard_rows(H, tile_rows, rank, world)
-        fb = torch.empty(rows * W * 3, dtype=torch.float32, device="cuda")
-        # two shard buffers per rank: frame f+1 renders while frame f is on its way to rank 0
-        exchange = sharding.TileExchange(dist, rank, world, H, W, tile_rows,
-                                         lambda n: torch.empty(n, dtype=torch.float32, device="cuda" if on_gpu else "cpu"), depth=2)
-    else:
-        fpl = max(1, min(32, args.frames_per_launch))
-        fb = torch.empty(fpl * H * W * 3, dtype=torch.float32, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
-
-    # pre-marshalled arguments: the timed loop is then one ctypes call per frame
-    import ctypes as C
-    L = api.lib()
-    fptr = C.POINTER(C.c_float)
-    cam_c = [np.ascontiguousarray(p, dtype=np.float32) for p, _ in poses]
-    cam_p = [a.ctypes.data_as(fptr) for a in cam_c]
-    trans_p = [a.ctypes.data_as(fptr) for a in trans]
-    fb_ptr, stream_p, handle = C.c_void_p(fb.data_ptr()), C.c_void_p(stream), scene._h
-
-    batch_cache = {}
-
-    def launch_frames(frames):
-        """One call = one launch for up to 32 frames of the path (frames stay resident in `fb`).
-        The marshalled pose arrays of a batch are built once (warm-up) and reused."""
-        key = tuple(frames)
-        if key not in batch_cache:
-            cams = np.ascontiguousarray(np.stack([cam_c[f] for f in frames]), dtype=np.float32)
-            trs = np.ascontiguousarray(np.stack([trans[f] for f in frames]), dtype=np.float32)
-            batch_cache[key] = (cams, trs, cams.ctypes.data_as(fptr), trs.ctypes.data_as(fptr), C.c_size_t(H * W * 3))
-        _, _, cp, tp, stride = batch_cache[key]
-        rc = L.rt_render_frames_device(handle, dev, len(frames), cp, tp, W, H, D, mode, fb_ptr, stride, stream_p)
-        if rc != 0:
-            raise api.RtError(rc, L.rt_last_error().decode())
-
-    def run_steps(frames):
-        """`len(frames)` steps (one step = one frame)."""
-        if tile_mode:
-            # row tiles: render this rank's interleaved tiles, then the one exchange step (RCCL), pipelined
-            for i, f in enumerate(frames):
-                buf = exchange.shard(i)
-                if on_gpu:
-                    scene.render_tiles_device(dev, poses[f][0], trans[f], W, H, D, mode, tile_rows, rank, world, buf.data_ptr(), stream)
-                else:   # gloo rehearsal: the shard is staged through host memory; RCCL sends it GPU to GPU
-                    scene.render_tiles_device(dev, poses[f][0], trans[f], W, H, D, mode, tile_rows, rank, world, fb.data_ptr(), stream)
-                    buf.copy_(fb)
-                exchange.submit(i)
-            exchange.drain()
-        else:
-            for i in range(0, len(frames), fpl):
-                launch_frames(frames[i:i + fpl])
-
-    run_steps([my_frames[s % len(my_frames)] for s in range(args.warmup)])
-    if not tile_mode:                       # marshal every batch of the timed loop ahead of it
-        for i in range(0, len(my_frames), fpl):
-            key = tuple(my_frames[i:i + fpl])
-            if key not in batch_cache:
-                launch_frames(list(key))
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    run_steps(my_frames)
-    ev1.record()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    n_launches = args.steps if tile_mode else (args.steps + fpl - 1) // fpl
-    kernel_ms = ev0.elapsed_time(ev1) / n_launches          # HIP events on the launch stream: mean launch duration
-
-    my_rays = float(sum(rays_of[f] for f in my_frames))
-    my_flops = float(sum(flops_of[f] for f in my_frames))
-    if dist:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
-        if not tile_mode:
-            r = torch.tensor([my_rays, my_flops], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
-            dist.all_reduce(r, op=dist.ReduceOp.SUM)
-            my_rays, my_flops = float(r[0].item()), float(r[1].item())
-    total_rays, total_flops = my_rays, my_flops
-
+        out = run_frames_mode(args, api, torch, dist, rank, world, dev, on_gpu, name)
     if rank == 0:
-        frames_total = args.steps if tile_mode else args.steps * world
-        flops_per_launch = sum(flops_of[f] for f in my_frames) / n_launches
-        achieved = flops_per_launch / (kernel_ms * 1e-3) / 1e12 if not tile_mode else None
-        out = {
-            "metric": "Mrays/s (primary+bounce+shadow) at 800x800" if args.workload.endswith("800") else "Mrays/s (primary+bounce+shadow)",
-            "value": total_rays / wall / 1e6,
-            "unit": "Mrays/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": wall / args.steps * 1e3,
-            "ms_per_frame": wall / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "strong" if tile_mode else "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": label, "accel": accel_name, "traversal": {0: None, 1: "per-lane", 2: "packet"}[scene.traversal(dev, trans[0], W, H)], "mode": args.mode, "width": W, "height": H, "max_bounces": D,
-                       "triangles": scene.n_triangles, "lights": scene.n_lights,
-                       "frames_per_launch": (fpl if not tile_mode else 1),
-                       "frames": ("64-pose camera sweep, frame (step*N + rank) mod 64, %d frames per launch" % fpl) if not tile_mode else "64-pose sweep, interleaved 16-row tiles, gather to rank 0",
-                       "rays_per_frame_mean": total_rays / frames_total, "parallelism": "frames x%d" % world if not tile_mode else "row tiles x%d" % world},
-        }
-        if achieved is not None:
-            out["roofline"] = {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                               "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": read_traffic(args.workload),
-                               "kernel_ms": kernel_ms,
-                               "flops_per_launch": flops_per_launch, "frames_per_launch": fpl, "launches": n_launches,
-                               "note": "FP32 VALU roofline (SURVEY 8d): nothing here is HBM- or MFMA-shaped; "
-                                       "algorithmic FLOPs = 14/plane + 6/point + 17/edge term + 22/box + 32|29|30 per ray"}
-        if world == 1 and not args.no_cpu:
-            cb = cpu_baseline(desc, args.cpu_seconds)
-            out["cpu_baseline"] = cb
-            threads = min(16, os.cpu_count() or 1)
-            mt = cpu_threaded(desc, threads)
-            out["cpu_threaded"] = {"value": cb["rays_per_frame"] / mt / 1e6, "unit": "Mrays/s",
-                                   "cores": threads, "kind": "port", "ms_per_frame": mt * 1e3,
-                                   "sample": "row-interleaved pthreads over the same frame (stands in for the reference's disabled std::execution::par loop)"}
-            out["gpu_over_cpu_1thread"] = out["value"] / cb["value"]
         print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
-    scene.close()
-
-
-def read_traffic(workload):
-    """HBM bytes per launch from the PMC passes kept under profiles/ (collected by
-    tools/profile.sh in separate rocprofv3 --pmc runs); None when no such pass exists."""
-    p = os.path.join(ROOT, "profiles", "traffic.json")
-    try:
-        with open(p) as f:
-            return json.load(f).get(workload)
-    except (OSError, ValueError):
-        return None
 
 
 if __name__ == "__main__":

@@ -40,11 +40,11 @@ extern "C" {
 #define RT_ACCEL_LBVH    2   /* GPU-built Morton/Karras LBVH                              */
 #define RT_BRUTE_AUTO_MAX 128   /* measured at 800x800 with packet traversal: 172 triangles 18.7 us brute vs 18.3 us LBVH, 972: 37 vs 26; room (26): 20 vs 25 */
 
-/* rt_render* flags */
-#define RT_RENDER_STRICT 0   /* unfused IEEE binary32 in the reference's operation order:
-                                bit-identical frames                                         */
-#define RT_RENDER_FAST   1   /* reserved for a tolerance-bound variant; today it runs the strict
-                                kernels (a contracted build measured 2-5 % faster: DESIGN.md 3) */
+/* rt_render* flags: the only mode is unfused IEEE binary32 in the reference's operation order —
+ * bit-identical frames.  (A contracted, tolerance-bound build was measured 2-5 % faster and moved
+ * the reference's diagonal seams by a pixel; it was dropped)  Any other value is
+ * RT_ERR_INVALID. */
+#define RT_RENDER_STRICT 0
 
 /* One triangle record as the reference stores it (Src:31-43), 28 floats:
  * p[3] n[3] p1[3] p2[3] p3[3] edge0[3] edge1[3] edge2[3] color[3] shininess */
@@ -118,6 +118,14 @@ int rt_scene_get_hoisted(const rt_scene* s, int device, int* out_indices, int ca
 
 /* The acceleration structure the last commit on `device` chose: RT_ACCEL_BRUTE or RT_ACCEL_LBVH. */
 int rt_scene_accel(const rt_scene* s, int device);
+
+/* Depth of the LBVH of the last commit on `device`: inner-node levels on the longest root-to-leaf
+ * path of the binary Karras tree (at most 63: the keys have 63 bits) and of its 4-wide collapse.
+ * The per-lane traversal keeps up to 3 entries per 4-wide level on its stack of RT_STACK_LIMIT
+ * entries; a tree with 3 * wide_depth > RT_STACK_LIMIT (nested geometry graded towards a point) is
+ * traversed by packets only, whose stack holds one entry per binary level.  Both 0 for brute force. */
+#define RT_STACK_LIMIT 64
+int rt_scene_bvh_depth(const rt_scene* s, int device, int* binary_depth, int* wide_depth);
 
 /* ---- camera (Src:1145-1147) ---------------------------------------------------------------- */
 
@@ -200,12 +208,28 @@ int rt_render_tiles_device(rt_scene* s, int device, const float cam_pos[3], cons
                            float* d_out_compact, void* hip_stream);
 int rt_shard_rows(int height, int tile_rows, int tile_first, int tile_stride);
 
+/* The hand-off to the viewer (Src:1270 uploads `data` every frame) without stalling the render:
+ * rt_render_async launches the frame on the scene's own render stream into one of two device frames
+ * and queues its copy to `out_rgb` on a second stream, then returns; while that copy runs the next
+ * rt_render_async already renders.  Returns a ticket >= 0; rt_render_wait(s, ticket) blocks until
+ * that frame (and every earlier one) is in `out_rgb`.  At most two frames are in flight: a third
+ * call first waits for the oldest.  `out_rgb` should come from rt_frame_alloc (pinned host memory:
+ * the copy then runs at PCIe speed and truly asynchronously; it is what replaces the malloc of
+ * Src:1035); pageable memory works but the copy is staged by the runtime.  Frames are rt_render's. */
+int rt_render_async(rt_scene* s, const float cam_pos[3], const float trans16[16], int width, int height,
+                    int max_bounces, int render_flags, float* out_rgb);
+int rt_render_wait(rt_scene* s, int ticket);
+/* Pinned host framebuffer of n_floats floats (replaces `data = malloc(...)`, Src:1035) / its release. */
+float* rt_frame_alloc(size_t n_floats);
+void   rt_frame_free(float* frame);
+
 /* Same frame as rt_render, additionally counting work (slower instrumented kernel). */
 int rt_render_stats(rt_scene* s, const float cam_pos[3], const float trans16[16], int width,
                     int height, int max_bounces, float* out_rgb /* may be NULL */, rt_stats* out);
 
 /* One process, several GPUs: commits the scene to devices[0..n) if needed, renders interleaved
- * row tiles on each and gathers the frame to host memory via devices[0]. */
+ * row tiles on each (tile t -> devices[t % n]), gathers the shards into the frame on devices[0]
+ * with peer-to-peer copies (xGMI) and copies it to host memory once from there. */
 int rt_render_multi(rt_scene* s, const int* devices, int n_devices, const float cam_pos[3],
                     const float trans16[16], int width, int height, int max_bounces,
                     int render_flags, int tile_rows, float* out_rgb);
@@ -215,20 +239,34 @@ int rt_render_multi(rt_scene* s, const int* devices, int n_devices, const float 
  * Host pointers; synchronous. */
 int rt_cast_rays(rt_scene* s, int n_rays, const float* rays7, float* out6);
 
+/* rt_cast_rays for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same
+ * arguments and results as rt_cast_rays, but the device copies of `rays7` and `out6` live in a
+ * buffer that is part of the library image (one per GPU, RT_NOALLOC_MAX_RAYS rays = 832 KiB, held
+ * until the process ends) instead of being hipMalloc'ed per call: the call allocates and frees
+ * nothing.  n_rays > RT_NOALLOC_MAX_RAYS is RT_ERR_LIMIT.  All calls on one GPU share that buffer:
+ * calls that overlap on one GPU race (serialise them); nothing in it needs to start at zero — a
+ * call overwrites the first n_rays slots of both halves and reads back only those. */
+#define RT_NOALLOC_MAX_RAYS 16384
+int rt_cast_rays_noalloc(rt_scene* s, int n_rays, const float* rays7, float* out6);
+
 /* ---- misc ---------------------------------------------------------------------------------- */
 
 int         rt_device_count(void);
 
-/* Tuning knob (process-wide): 8x8 pixel tiles each wavefront walks; 0 = library default. */
-int         rt_set_tiles_per_wave(int tiles);
-/* Tuning knob (process-wide): how LBVH scenes are traversed.  RT_TRAVERSAL_AUTO lets each launch
- * choose by the coherence of an 8x8 tile of rays against the scene's triangles;
- * both give the reference's bits. */
+/* Tuning knob of one scene: 8x8 pixel tiles each wavefront walks; 0 = the launcher's rule, at
+ * most RT_TILES_PER_WAVE_MAX.  Pixels do not depend on it. */
+#define RT_TILES_PER_WAVE_MAX 1024
+int         rt_scene_set_tiles_per_wave(rt_scene* s, int tiles);
+/* Tuning knob of one scene: how its LBVH is traversed.  RT_TRAVERSAL_AUTO lets each launch choose
+ * by the coherence of an 8x8 tile of rays against the scene's triangles; both give
+ * the reference's bits.  A preference: a tree too deep for the per-lane stack (rt_scene_bvh_depth)
+ * is walked by packets whatever is asked; rt_scene_traversal tells what a launch really gets. */
 #define RT_TRAVERSAL_AUTO     0
 #define RT_TRAVERSAL_PER_LANE 1   /* every lane walks the 4-wide tree with its own stack */
-#define RT_TRAVERSAL_PACKET   2   /* one walk of the binary tree per wavefront (falls back per wave when rays diverge) */
-int         rt_set_traversal(int mode);
-/* Which traversal a frame of this size and pose would get on `device`: RT_TRAVERSAL_PER_LANE or
+#define RT_TRAVERSAL_PACKET   2   /* one walk of the binary tree per wavefront and direction octant */
+int         rt_scene_set_traversal(rt_scene* s, int mode);
+/* Which traversal a frame of this size and pose gets on `device`: RT_TRAVERSAL_PER_LANE or
  * RT_TRAVERSAL_PACKET for an LBVH commit, 0 for a brute-force commit. */
 int         rt_scene_traversal(const rt_scene* s, int device, const float trans16[16], int width, int height);
 const char* rt_last_error(void);

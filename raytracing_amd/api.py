@@ -22,7 +22,9 @@ LIB_PATH = os.environ.get("RT355_LIB") or os.path.join(_HERE, "librt355.so")   #
 RT_OK = 0
 ACCEL_AUTO, ACCEL_BRUTE, ACCEL_LBVH = 0, 1, 2
 TRAVERSAL_AUTO, TRAVERSAL_PER_LANE, TRAVERSAL_PACKET = 0, 1, 2
-STRICT, FAST = 0, 1
+STRICT = 0            # RT_RENDER_STRICT: the only render mode (bit-identical frames)
+STACK_LIMIT = 64      # RT_STACK_LIMIT
+NOALLOC_MAX_RAYS = 16384
 TRI_FLOATS = 28
 
 ERROR_NAMES = {-1: "RT_ERR_INVALID", -2: "RT_ERR_STATE", -3: "RT_ERR_DEVICE", -4: "RT_ERR_NOMEM",
@@ -33,10 +35,11 @@ SYMBOLS = (
     "rt_scene_create", "rt_scene_destroy", "rt_scene_clear", "rt_scene_add_triangle",
     "rt_scene_add_triangles", "rt_scene_add_quad_half", "rt_scene_add_light", "rt_scene_load_rto",
     "rt_scene_triangle_count", "rt_scene_light_count", "rt_scene_get_triangles", "rt_scene_commit",
-    "rt_scene_build_ms", "rt_scene_get_bvh", "rt_scene_get_hoisted", "rt_scene_accel", "rt_camera_trans", "rt_camera_init", "rt_camera_rotate",
+    "rt_scene_build_ms", "rt_scene_get_bvh", "rt_scene_get_hoisted", "rt_scene_accel", "rt_scene_bvh_depth", "rt_camera_trans", "rt_camera_init", "rt_camera_rotate",
     "rt_camera_translate", "rt_camera_frame_time", "rt_camera_step", "rt_camera_path", "rt_render", "rt_render_device",
     "rt_render_frames_device", "rt_render_tiles_device", "rt_shard_rows", "rt_render_stats", "rt_render_multi", "rt_cast_rays",
-    "rt_device_count", "rt_set_tiles_per_wave", "rt_set_traversal", "rt_scene_traversal", "rt_last_error", "rt_version",
+    "rt_render_async", "rt_render_wait", "rt_frame_alloc", "rt_frame_free", "rt_cast_rays_noalloc",
+    "rt_device_count", "rt_scene_set_tiles_per_wave", "rt_scene_set_traversal", "rt_scene_traversal", "rt_last_error", "rt_version",
 )
 
 
@@ -142,8 +145,16 @@ def lib():
     L.rt_render_multi.argtypes = [vp, C.POINTER(ci), ci, _fp, _fp, ci, ci, ci, ci, ci, _fp]
     L.rt_cast_rays.argtypes = [vp, ci, _fp, _fp]
     L.rt_device_count.argtypes = []
-    L.rt_set_tiles_per_wave.argtypes = [ci]
-    L.rt_set_traversal.argtypes = [ci]
+    L.rt_scene_set_tiles_per_wave.argtypes = [vp, ci]
+    L.rt_scene_set_traversal.argtypes = [vp, ci]
+    L.rt_scene_bvh_depth.argtypes = [vp, ci, C.POINTER(ci), C.POINTER(ci)]
+    L.rt_render_async.argtypes = [vp, _fp, _fp, ci, ci, ci, ci, vp]
+    L.rt_render_wait.argtypes = [vp, ci]
+    L.rt_frame_alloc.restype = vp
+    L.rt_frame_alloc.argtypes = [C.c_size_t]
+    L.rt_frame_free.restype = None
+    L.rt_frame_free.argtypes = [vp]
+    L.rt_cast_rays_noalloc.argtypes = [vp, ci, _fp, _fp]
     L.rt_scene_traversal.argtypes = [vp, ci, _fp, ci, ci]
     L.rt_last_error.restype = C.c_char_p
     L.rt_last_error.argtypes = []
@@ -169,9 +180,32 @@ def _p(a: np.ndarray):
     return a.ctypes.data_as(_fp)
 
 
-def set_traversal(mode: int) -> None:
-    """How LBVH scenes are traversed (rt_set_traversal): TRAVERSAL_AUTO | _PER_LANE | _PACKET."""
-    _check(lib().rt_set_traversal(int(mode)))
+class HostFrame:
+    """A pinned host framebuffer (rt_frame_alloc: what replaces `data = malloc(...)`, Source.cpp:1035)
+    as an (H, W, 3) float32 array; rt_render_async copies into it at PCIe speed."""
+
+    def __init__(self, width: int, height: int):
+        n = int(width) * int(height) * 3
+        self._p = lib().rt_frame_alloc(n)
+        if not self._p:
+            raise RtError(-4, lib().rt_last_error().decode())
+        self.array = np.ctypeslib.as_array(C.cast(self._p, _fp), shape=(n,)).reshape(int(height), int(width), 3)
+
+    @property
+    def ptr(self) -> int:
+        return int(self._p)
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self.array = None
+            lib().rt_frame_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def device_count() -> int:
@@ -188,6 +222,15 @@ def camera_trans(rot_deg: Sequence[float]) -> np.ndarray:
 
 def shard_rows(height: int, tile_rows: int, tile_first: int, tile_stride: int) -> int:
     return int(lib().rt_shard_rows(height, tile_rows, tile_first, tile_stride))
+
+
+def camera_sweep(n_frames: int = 64, pos=(-5.0, 5.0, 5.0), rot=(135.0, -45.0, 0.0), frame_ms: float = 16.0):
+    """BASELINE config 5's deterministic camera path, walked by the reference's own controller
+    (rt_camera_path: Camera::rotate / translate, Source.cpp:144-209, speeds from the frame time,
+    Source.cpp:1307-1308): look right + move forward held down, every frame reported as `frame_ms`
+    (the first step moves with the base speeds the reference starts with, Source.cpp:109-112).
+    -> (cam_pos (n,3), trans (n,16)) float32, the pose each frame is drawn with."""
+    return Camera(pos, rot).path([KEY_LOOK_RIGHT | KEY_FORWARD] * int(n_frames), [float(frame_ms)] * int(n_frames))
 
 
 # key flags of Source.cpp:237-241 (rt355.h RT_KEY_*)
@@ -358,6 +401,21 @@ class Scene:
     def accel(self, device: int = 0) -> int:
         return _check(lib().rt_scene_accel(self._h, int(device)))
 
+    def set_traversal(self, mode: int) -> "Scene":
+        """How this scene's LBVH is traversed (rt_scene_set_traversal): TRAVERSAL_AUTO | _PER_LANE | _PACKET."""
+        _check(lib().rt_scene_set_traversal(self._h, int(mode)))
+        return self
+
+    def set_tiles_per_wave(self, tiles: int) -> "Scene":
+        _check(lib().rt_scene_set_tiles_per_wave(self._h, int(tiles)))
+        return self
+
+    def bvh_depth(self, device: int = 0):
+        """(binary depth, 4-wide depth) of the LBVH (rt_scene_bvh_depth); (0, 0) for brute force."""
+        a, b = C.c_int(0), C.c_int(0)
+        _check(lib().rt_scene_bvh_depth(self._h, int(device), C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def bvh(self, device: int = 0) -> np.ndarray:
         """(triangles in the tree - 1, 16) float32 LBVH nodes (see rt_scene_get_bvh); empty for a brute-force commit."""
         n = _check(lib().rt_scene_get_bvh(self._h, int(device), None, 0))
@@ -387,6 +445,15 @@ class Scene:
         out = np.empty((height, width, 3), dtype=np.float32)
         _check(lib().rt_render(self._h, _p(cam), _p(tr), width, height, max_bounces, mode, _p(out)))
         return out
+
+    def render_async(self, cam_pos, trans16, width: int, height: int, max_bounces: int, out: "HostFrame") -> int:
+        """rt_render_async into a pinned HostFrame (or any float32 array of the frame's size) -> ticket."""
+        cam, tr = _f32(cam_pos), _f32(trans16)
+        ptr = out.ptr if isinstance(out, HostFrame) else out.ctypes.data
+        return _check(lib().rt_render_async(self._h, _p(cam), _p(tr), width, height, max_bounces, STRICT, C.c_void_p(ptr)))
+
+    def render_wait(self, ticket: int) -> None:
+        _check(lib().rt_render_wait(self._h, int(ticket)))
 
     def render_stats(self, cam_pos, trans16, width: int, height: int, max_bounces: int = 1,
                      want_frame: bool = True):
@@ -429,7 +496,8 @@ class Scene:
 
     def render_multi(self, devices: Iterable[int], cam_pos, trans16, width: int, height: int,
                      max_bounces: int = 1, mode: int = STRICT, tile_rows: int = 16) -> np.ndarray:
-        devs = (C.c_int * len(list(devices)))(*list(devices))
+        devs_l = [int(x) for x in devices]
+        devs = (C.c_int * len(devs_l))(*devs_l)
         cam, tr = _f32(cam_pos), _f32(trans16)
         out = np.empty((height, width, 3), dtype=np.float32)
         _check(lib().rt_render_multi(self._h, devs, len(devs), _p(cam), _p(tr), width, height, max_bounces,
@@ -444,10 +512,20 @@ class Scene:
         _check(lib().rt_cast_rays(self._h, r.shape[0], _p(r), _p(out)))
         return out
 
+    def cast_rays_noalloc(self, rays7) -> np.ndarray:
+        """cast_rays through rt_cast_rays_noalloc (staging inside the library image, no device allocation);
+        at most NOALLOC_MAX_RAYS rays."""
+        r = _f32(rays7).reshape(-1, 7)
+        out = np.zeros((r.shape[0], 6), dtype=np.float32)
+        _check(lib().rt_cast_rays_noalloc(self._h, r.shape[0], _p(r), _p(out)))
+        return out
 
-def render_desc(desc, device: int = 0, accel: int = ACCEL_AUTO, mode: int = STRICT) -> np.ndarray:
+
+def render_desc(desc, device: int = 0, accel: int = ACCEL_AUTO, mode: int = STRICT,
+                traversal: int = TRAVERSAL_AUTO) -> np.ndarray:
     """Scene description -> frame, the way the reference's main() would: build, commit, render."""
     with Scene.from_desc(desc) as sc:
+        sc.set_traversal(traversal)
         sc.commit(device, accel)
         return sc.render(desc.cam_pos, camera_trans(desc.cam_rot), desc.width, desc.height, desc.depth, mode)
 

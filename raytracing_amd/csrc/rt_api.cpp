@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 
 namespace rt {
 
@@ -68,6 +69,14 @@ void free_device_state(DeviceState& d) {
 		if (d.lights) (void)hipFree(d.lights);
 		if (d.counters) (void)hipFree(d.counters);
 		if (d.frame) (void)hipFree(d.frame);
+		if (d.gather) (void)hipFree(d.gather);
+		for (int k = 0; k < 2; k++) {
+			if (d.aframe[k]) (void)hipFree(d.aframe[k]);
+			if (d.rendered[k]) (void)hipEventDestroy(d.rendered[k]);
+			if (d.copied[k]) (void)hipEventDestroy(d.copied[k]);
+		}
+		if (d.render_stream) { (void)hipStreamSynchronize(d.render_stream); (void)hipStreamDestroy(d.render_stream); }
+		if (d.copy_stream) { (void)hipStreamSynchronize(d.copy_stream); (void)hipStreamDestroy(d.copy_stream); }
 		lbvh_free(d);
 	}
 	if (prev >= 0) (void)hipSetDevice(prev);
@@ -79,6 +88,11 @@ int check_frame_args(const char* fn, const rt_scene* s, const float* cam, const 
 	if (w <= 0 || h <= 0) { set_error("%s: width and height must be positive (got %dx%d)", fn, w, h); return RT_ERR_INVALID; }
 	if ((long long)w * h > 0x7fffffffLL / 3) { set_error("%s: %dx%d overflows the reference's int pixel index (Source.cpp:550)", fn, w, h); return RT_ERR_LIMIT; }
 	if (depth < 0) { set_error("%s: max_bounces must be >= 0", fn); return RT_ERR_INVALID; }
+	return RT_OK;
+}
+
+int check_flags(const char* fn, int render_flags) {
+	if (render_flags != RT_RENDER_STRICT) { set_error("%s: unknown render flag %d (RT_RENDER_STRICT is the only mode)", fn, render_flags); return RT_ERR_INVALID; }
 	return RT_OK;
 }
 
@@ -119,11 +133,42 @@ int ensure_frame(DeviceState& d, size_t bytes) {
 	return RT_OK;
 }
 
-int g_tiles_per_wave_override = 0;
+int ensure_buffer(void*& p, size_t& have, size_t bytes) {
+	if (have >= bytes) return RT_OK;
+	if (p) { (void)hipFree(p); p = nullptr; have = 0; }
+	RT_HIP(hipMalloc(&p, bytes));
+	have = bytes;
+	return RT_OK;
+}
+
+// ---- rt_cast_rays_noalloc: staging that is part of the library image ---------------------------
+// The device copies of the caller's rays and of the results live in this file-scope array instead
+// of per-call hipMalloc'ed buffers: rays at float offset 0 (7 per ray), results behind them (6 per
+// ray).  In host code the NAME `scratch` is only a stand-in for the symbol: each GPU the code
+// object is loaded on holds its own copy at its own address, looked up once per device with
+// hipGetSymbolAddress while that device is current; host code uses only the looked-up pointer.
+#define RT_SCRATCH_FLOATS ((size_t)RT_NOALLOC_MAX_RAYS * 13)
+static __device__ __align__(256) float scratch[RT_SCRATCH_FLOATS];
+#define RT_MAX_DEVICES 64
+std::mutex g_scratch_mutex;
+float* g_scratch_ptr[RT_MAX_DEVICES];          // per HIP device ordinal; nullptr until looked up
+
+// `device` must be current.
+int scratch_for_device(int device, float** out) {
+	if (device < 0 || device >= RT_MAX_DEVICES) { set_error("device %d beyond the %d the no-allocation path keeps a buffer for", device, RT_MAX_DEVICES); return RT_ERR_LIMIT; }
+	std::lock_guard<std::mutex> lock(g_scratch_mutex);
+	if (!g_scratch_ptr[device]) {
+		void* p = nullptr;
+		hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+		if (e != hipSuccess) return hip_fail(e, "hipGetSymbolAddress(scratch)");
+		if (!p) { set_error("hipGetSymbolAddress(scratch) returned a null address on device %d", device); return RT_ERR_DEVICE; }
+		g_scratch_ptr[device] = (float*)p;
+	}
+	*out = g_scratch_ptr[device];
+	return RT_OK;
+}
 
 } // namespace
-
-int g_traversal_mode = RT_TRAVERSAL_AUTO;      // rt_set_traversal; read by the launchers in rt_kernels.hip
 
 } // namespace rt
 
@@ -154,14 +199,27 @@ int rt_scene_traversal(const rt_scene* s, int device, const float trans16[16], i
 	return use_packets(dev_scene(s, it->second), trans16, width, height) ? RT_TRAVERSAL_PACKET : RT_TRAVERSAL_PER_LANE;
 }
 
-int rt_set_traversal(int mode) {
-	if (mode < RT_TRAVERSAL_AUTO || mode > RT_TRAVERSAL_PACKET) { set_error("rt_set_traversal: unknown mode %d", mode); return RT_ERR_INVALID; }
-	g_traversal_mode = mode;
+int rt_scene_set_traversal(rt_scene* s, int mode) {
+	if (!s) { set_error("rt_scene_set_traversal: NULL scene"); return RT_ERR_INVALID; }
+	if (mode < RT_TRAVERSAL_AUTO || mode > RT_TRAVERSAL_PACKET) { set_error("rt_scene_set_traversal: unknown mode %d", mode); return RT_ERR_INVALID; }
+	s->traversal = mode;
 	return RT_OK;
 }
 
-int rt_set_tiles_per_wave(int tiles) {
-	g_tiles_per_wave_override = tiles < 0 ? 0 : tiles;
+int rt_scene_set_tiles_per_wave(rt_scene* s, int tiles) {
+	if (!s) { set_error("rt_scene_set_tiles_per_wave: NULL scene"); return RT_ERR_INVALID; }
+	if (tiles < 0 || tiles > RT_TILES_PER_WAVE_MAX) { set_error("rt_scene_set_tiles_per_wave: %d is outside [0, %d]", tiles, RT_TILES_PER_WAVE_MAX); return RT_ERR_INVALID; }
+	s->tiles_per_wave = tiles;
+	return RT_OK;
+}
+
+int rt_scene_bvh_depth(const rt_scene* s, int device, int* binary_depth, int* wide_depth) {
+	if (!s || !binary_depth || !wide_depth) { set_error("rt_scene_bvh_depth: NULL argument"); return RT_ERR_INVALID; }
+	auto it = s->dev.find(device);
+	if (it == s->dev.end() || !it->second.valid) { set_error("rt_scene_bvh_depth: not committed on device %d", device); return RT_ERR_STATE; }
+	const bool tree = it->second.accel == RT_ACCEL_LBVH;
+	*binary_depth = tree ? it->second.bvh_depth : 0;
+	*wide_depth = tree ? it->second.bvh4_depth : 0;
 	return RT_OK;
 }
 
@@ -226,6 +284,11 @@ int rt_scene_commit(rt_scene* s, int device, int accel_flags) {
 		int rc = lbvh_build(s, d, nullptr);
 		if (rc != RT_OK) return rc;
 	}
+	{   // set-up for rt_cast_rays_noalloc: this device's address of the library's staging array
+		float* unused = nullptr;
+		int rc = scratch_for_device(device, &unused);
+		if (rc != RT_OK && rc != RT_ERR_LIMIT) return rc;
+	}
 	d.valid = true;
 	if (s->first_device < 0 || !s->dev.count(s->first_device) || !s->dev[s->first_device].valid) s->first_device = device;
 	return RT_OK;
@@ -281,7 +344,7 @@ int rt_render_tiles_device(rt_scene* s, int device, const float cam_pos[3], cons
 	if (rc != RT_OK) return rc;
 	if (!d_out_compact) { set_error("rt_render_tiles_device: NULL output"); return RT_ERR_INVALID; }
 	if (tile_rows <= 0 || tile_first < 0 || tile_stride <= 0) { set_error("rt_render_tiles_device: bad tile parameters"); return RT_ERR_INVALID; }
-	if (render_flags != RT_RENDER_STRICT && render_flags != RT_RENDER_FAST) { set_error("rt_render_tiles_device: unknown render flag %d", render_flags); return RT_ERR_INVALID; }
+	if ((rc = check_flags("rt_render_tiles_device", render_flags)) != RT_OK) return rc;
 	DeviceGuard g(device);
 	if (!g.ok) return g.rc;
 	DeviceState* d = committed("rt_render_tiles_device", s, device);
@@ -292,7 +355,7 @@ int rt_render_tiles_device(rt_scene* s, int device, const float cam_pos[3], cons
 	fp.tile_first = tile_first;
 	fp.tile_stride = tile_stride;
 	fp.local_rows = rt_shard_rows(height, tile_rows, tile_first, tile_stride);
-	fp.tiles_per_wave = g_tiles_per_wave_override;
+	fp.tiles_per_wave = s->tiles_per_wave;
 	fp.out = d_out_compact;
 	return launch_render(dev_scene(s, *d), fp, d->accel, render_flags, false, (hipStream_t)hip_stream);
 }
@@ -306,7 +369,7 @@ int rt_render_frames_device(rt_scene* s, int device, int n_frames, const float* 
 	if (rc != RT_OK) return rc;
 	if (!d_out_rgb) { set_error("rt_render_frames_device: NULL output"); return RT_ERR_INVALID; }
 	if (frame_stride_floats < (size_t)width * height * 3) { set_error("rt_render_frames_device: frame stride smaller than a frame"); return RT_ERR_INVALID; }
-	if (render_flags != RT_RENDER_STRICT && render_flags != RT_RENDER_FAST) { set_error("rt_render_frames_device: unknown render flag %d", render_flags); return RT_ERR_INVALID; }
+	if ((rc = check_flags("rt_render_frames_device", render_flags)) != RT_OK) return rc;
 	DeviceGuard g(device);
 	if (!g.ok) return g.rc;
 	DeviceState* d = committed("rt_render_frames_device", s, device);
@@ -322,7 +385,7 @@ int rt_render_frames_device(rt_scene* s, int device, int n_frames, const float* 
 		}
 		fp.n_frames = nf;
 		fp.frame_stride = (long long)frame_stride_floats;
-		fp.tiles_per_wave = g_tiles_per_wave_override;
+		fp.tiles_per_wave = s->tiles_per_wave;
 		fp.out = d_out_rgb + (size_t)f0 * frame_stride_floats;
 		rc = launch_render(sc, fp, d->accel, render_flags, false, (hipStream_t)hip_stream);
 		if (rc != RT_OK) return rc;
@@ -386,7 +449,7 @@ int rt_render_stats(rt_scene* s, const float cam_pos[3], const float trans16[16]
 	RT_HIP(hipMemsetAsync(d->counters, 0, 32 * sizeof(unsigned long long), nullptr));
 	FrameParams fp;
 	fill_frame(fp, cam_pos, trans16, width, height, max_bounces);
-	fp.tiles_per_wave = g_tiles_per_wave_override;
+	fp.tiles_per_wave = s->tiles_per_wave;
 	fp.out = (float*)d->frame;
 	fp.counters = (unsigned long long*)d->counters;
 #ifdef RT_PROFILE
@@ -434,6 +497,8 @@ int rt_render_multi(rt_scene* s, const int* devices, int n_devices, const float 
 	}
 	// 2. every device renders its interleaved row tiles into a compact buffer (its scratch frame)
 	const size_t row_bytes = (size_t)width * 3 * sizeof(float);
+	const size_t frame_bytes = row_bytes * (size_t)height;
+	const int root = devices[0];
 	std::vector<hipStream_t> streams((size_t)n_devices, nullptr);
 	auto cleanup = [&]() {
 		for (int k = 0; k < n_devices; k++)
@@ -441,6 +506,19 @@ int rt_render_multi(rt_scene* s, const int* devices, int n_devices, const float 
 	};
 	int prev = -1;
 	(void)hipGetDevice(&prev);
+	// the frame the shards are gathered into lives on devices[0]
+	if (hipSetDevice(root) != hipSuccess) { set_error("rt_render_multi: hipSetDevice(%d) failed", root); (void)hipGetLastError(); return RT_ERR_DEVICE; }
+	{
+		DeviceState& d0 = s->dev[root];
+		rc = ensure_buffer(d0.gather, d0.gather_bytes, frame_bytes);
+	}
+	for (int k = 1; k < n_devices && rc == RT_OK; k++) {
+		// let devices[k] write into devices[0]'s memory directly (xGMI); already enabled is fine
+		int can = 0;
+		if (hipDeviceCanAccessPeer(&can, devices[k], root) == hipSuccess && can && hipSetDevice(devices[k]) == hipSuccess)
+			(void)hipDeviceEnablePeerAccess(root, 0);        // (without it the peer copy below is staged through the host)
+		(void)hipGetLastError();
+	}
 	for (int k = 0; k < n_devices && rc == RT_OK; k++) {
 		DeviceState& d = s->dev[devices[k]];
 		const int rows = rt_shard_rows(height, tile_rows, k, n_devices);
@@ -451,17 +529,18 @@ int rt_render_multi(rt_scene* s, const int* devices, int n_devices, const float 
 		if (rc != RT_OK) break;
 		rc = rt_render_tiles_device(s, devices[k], cam_pos, trans16, width, height, max_bounces, render_flags,
 		                            tile_rows, k, n_devices, (float*)d.frame, streams[k]);
-	}
-	// 3. gather: each shard's tiles go straight to their rows of the caller's frame
-	for (int k = 0; k < n_devices && rc == RT_OK; k++) {
-		DeviceState& d = s->dev[devices[k]];
-		(void)hipSetDevice(devices[k]);
+		if (rc != RT_OK) break;
+		// 3. the exchange step: this shard's tiles go straight to their rows of the frame on devices[0],
+		//    queued behind the render on the same stream (7 concurrent xGMI transfers into GPU 0 on a full node)
+		char* const dst0 = (char*)s->dev[root].gather;
 		size_t src_row = 0;
 		for (long long t = k; t * tile_rows < height && rc == RT_OK; t += n_devices) {
 			long long r0 = t * tile_rows, r1 = r0 + tile_rows;
 			if (r1 > height) r1 = height;
-			hipError_t e = hipMemcpyAsync((char*)out_rgb + (size_t)r0 * row_bytes, (const char*)d.frame + src_row * row_bytes,
-			                              (size_t)(r1 - r0) * row_bytes, hipMemcpyDeviceToHost, streams[k]);
+			const size_t bytes = (size_t)(r1 - r0) * row_bytes;
+			hipError_t e = devices[k] == root
+				? hipMemcpyAsync(dst0 + (size_t)r0 * row_bytes, (const char*)d.frame + src_row * row_bytes, bytes, hipMemcpyDeviceToDevice, streams[k])
+				: hipMemcpyPeerAsync(dst0 + (size_t)r0 * row_bytes, root, (const char*)d.frame + src_row * row_bytes, devices[k], bytes, streams[k]);
 			if (e != hipSuccess) rc = hip_fail(e, "rt_render_multi gather");
 			src_row += (size_t)(r1 - r0);
 		}
@@ -472,9 +551,86 @@ int rt_render_multi(rt_scene* s, const int* devices, int n_devices, const float 
 		hipError_t e = hipStreamSynchronize(streams[k]);
 		if (e != hipSuccess && rc == RT_OK) rc = hip_fail(e, "rt_render_multi sync");
 	}
+	// 4. one copy of the gathered frame from devices[0] to the caller
+	if (rc == RT_OK) {
+		(void)hipSetDevice(root);
+		hipError_t e = hipMemcpy(out_rgb, s->dev[root].gather, frame_bytes, hipMemcpyDeviceToHost);
+		if (e != hipSuccess) rc = hip_fail(e, "rt_render_multi copy to host");
+	}
 	cleanup();
 	if (prev >= 0) (void)hipSetDevice(prev);
 	return rc;
+}
+
+// ---- the hand-off to the viewer, pipelined (Source.cpp:1270) -------------------------------------
+
+float* rt_frame_alloc(size_t n_floats) {
+	void* p = nullptr;
+	hipError_t e = hipHostMalloc(&p, (n_floats > 0 ? n_floats : 1) * sizeof(float), hipHostMallocDefault);
+	if (e != hipSuccess) { (void)hip_fail(e, "hipHostMalloc (rt_frame_alloc)"); return nullptr; }
+	return (float*)p;
+}
+
+void rt_frame_free(float* frame) {
+	if (frame) { (void)hipHostFree(frame); (void)hipGetLastError(); }
+}
+
+int rt_render_async(rt_scene* s, const float cam_pos[3], const float trans16[16], int width, int height,
+                    int max_bounces, int render_flags, float* out_rgb) {
+	int rc = check_frame_args("rt_render_async", s, cam_pos, trans16, width, height, max_bounces);
+	if (rc != RT_OK) return rc;
+	if (!out_rgb) { set_error("rt_render_async: NULL output"); return RT_ERR_INVALID; }
+	if ((rc = check_flags("rt_render_async", render_flags)) != RT_OK) return rc;
+	if (s->first_device < 0) { set_error("rt_render_async: scene is not committed to any device"); return RT_ERR_STATE; }
+	const int device = s->first_device;
+	DeviceGuard g(device);
+	if (!g.ok) return g.rc;
+	DeviceState* d = committed("rt_render_async", s, device);
+	if (!d) return RT_ERR_STATE;
+	if (s->next_ticket >= 0x7fffffffLL) { set_error("rt_render_async: ticket counter exhausted"); return RT_ERR_LIMIT; }
+	if (!d->render_stream) {
+		RT_HIP(hipStreamCreateWithFlags(&d->render_stream, hipStreamNonBlocking));
+		RT_HIP(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
+		for (int k = 0; k < 2; k++) {
+			RT_HIP(hipEventCreateWithFlags(&d->rendered[k], hipEventDisableTiming));
+			RT_HIP(hipEventCreateWithFlags(&d->copied[k], hipEventDisableTiming));
+		}
+	}
+	const long long ticket = s->next_ticket;
+	const int slot = (int)(ticket & 1);
+	const size_t bytes = (size_t)width * height * 3 * sizeof(float);
+	if (d->ticket_of_slot[slot] >= 0) {
+		// the device frame of this slot is free once its copy (two frames ago) has finished
+		if (d->aframe_bytes[slot] < bytes) RT_HIP(hipEventSynchronize(d->copied[slot]));   // about to be reallocated
+		else RT_HIP(hipStreamWaitEvent(d->render_stream, d->copied[slot], 0));
+	}
+	rc = ensure_buffer(d->aframe[slot], d->aframe_bytes[slot], bytes);
+	if (rc != RT_OK) return rc;
+	rc = rt_render_device(s, device, cam_pos, trans16, width, height, max_bounces, render_flags, (float*)d->aframe[slot], d->render_stream);
+	if (rc != RT_OK) return rc;
+	RT_HIP(hipEventRecord(d->rendered[slot], d->render_stream));
+	RT_HIP(hipStreamWaitEvent(d->copy_stream, d->rendered[slot], 0));
+	RT_HIP(hipMemcpyAsync(out_rgb, d->aframe[slot], bytes, hipMemcpyDeviceToHost, d->copy_stream));
+	RT_HIP(hipEventRecord(d->copied[slot], d->copy_stream));
+	d->ticket_of_slot[slot] = ticket;
+	s->next_ticket = ticket + 1;
+	return (int)ticket;
+}
+
+int rt_render_wait(rt_scene* s, int ticket) {
+	if (!s) { set_error("rt_render_wait: NULL scene"); return RT_ERR_INVALID; }
+	if (ticket < 0 || ticket >= s->next_ticket) { set_error("rt_render_wait: ticket %d was not issued", ticket); return RT_ERR_INVALID; }
+	if (s->first_device < 0) { set_error("rt_render_wait: scene is not committed to any device"); return RT_ERR_STATE; }
+	auto it = s->dev.find(s->first_device);
+	if (it == s->dev.end() || !it->second.copy_stream) { set_error("rt_render_wait: no frame in flight (the scene was committed again?)"); return RT_ERR_STATE; }
+	DeviceState& d = it->second;
+	DeviceGuard g(d.device);
+	if (!g.ok) return g.rc;
+	// copies complete in ticket order on the one copy stream: waiting for the slot that holds this
+	// ticket (or a later one that re-used it) covers it and every earlier frame
+	const int slot = ticket & 1;
+	if (d.ticket_of_slot[slot] >= ticket) RT_HIP(hipEventSynchronize(d.copied[slot]));
+	return RT_OK;
 }
 
 int rt_cast_rays(rt_scene* s, int n_rays, const float* rays7, float* out6) {
@@ -501,6 +657,31 @@ int rt_cast_rays(rt_scene* s, int n_rays, const float* rays7, float* out6) {
 	(void)hipFree(dr);
 	(void)hipFree(dout);
 	return rc;
+}
+
+int rt_cast_rays_noalloc(rt_scene* s, int n_rays, const float* rays7, float* out6) {
+	if (!s || n_rays < 0 || (n_rays > 0 && (!rays7 || !out6))) { set_error("rt_cast_rays_noalloc: bad argument"); return RT_ERR_INVALID; }
+	if (n_rays > RT_NOALLOC_MAX_RAYS) {
+		set_error("rt_cast_rays_noalloc: %d rays exceed the %d the library's own staging buffer holds (split the batch, or use rt_cast_rays)", n_rays, RT_NOALLOC_MAX_RAYS);
+		return RT_ERR_LIMIT;
+	}
+	if (s->first_device < 0) { set_error("rt_cast_rays_noalloc: scene is not committed to any device"); return RT_ERR_STATE; }
+	if (n_rays == 0) return RT_OK;
+	const int device = s->first_device;
+	DeviceGuard g(device);
+	if (!g.ok) return g.rc;
+	DeviceState* d = committed("rt_cast_rays_noalloc", s, device);
+	if (!d) return RT_ERR_STATE;
+	float* base = nullptr;                         // this device's copy of `scratch` (looked up at commit, else here)
+	int rc = scratch_for_device(device, &base);
+	if (rc != RT_OK) return rc;
+	float* const dr = base;                                              // n_rays x 7
+	float* const dout = base + (size_t)RT_NOALLOC_MAX_RAYS * 7;          // n_rays x 6
+	RT_HIP(hipMemcpy(dr, rays7, (size_t)n_rays * 7 * sizeof(float), hipMemcpyHostToDevice));
+	rc = launch_cast_rays(dev_scene(s, *d), d->accel, n_rays, dr, dout, nullptr);
+	if (rc != RT_OK) return rc;
+	RT_HIP(hipMemcpy(out6, dout, (size_t)n_rays * 6 * sizeof(float), hipMemcpyDeviceToHost));
+	return RT_OK;
 }
 
 } // extern "C"

@@ -76,6 +76,8 @@ struct DevScene {
 	float bb_lo[3], bb_hi[3];
 	float far_guard;        // |origin| beyond this: the box tests are switched off for the ray
 	float packet_scale;     // scene diagonal / mean triangle box diagonal (launcher: is an 8x8 tile of rays coherent?)
+	int traversal;          // rt_scene_set_traversal: RT_TRAVERSAL_AUTO | _PER_LANE | _PACKET (host side only)
+	int per_lane_ok;        // 0: the 4-wide tree is too deep for the per-lane stack (RT_STACK_MAX); packets only
 };
 
 // Per-launch frame description.  Rows are addressed as LOCAL rows of this shard:
@@ -122,6 +124,9 @@ struct DeviceState {
 	void* hoist = nullptr;
 	int hoist_count = 0;
 	int bvh_node_count = 0;      // inner nodes of the binary tree (triangles in the tree - 1)
+	int bvh_depth = 0;           // levels of inner nodes on the longest root-to-leaf path of the binary tree
+	int bvh4_depth = 0;          // the same for the 4-wide collapse the per-lane traversal walks
+	bool per_lane_ok = true;     // 3 * bvh4_depth fits the per-lane stack (rt_lbvh_trav.inl RT_STACK_MAX)
 	std::vector<int> hoisted;    // triangle indices kept out of the tree, ascending
 	float packet_scale = 0.f;
 	void* counters = nullptr;
@@ -134,11 +139,18 @@ struct DeviceState {
 	int n_clusters = 0;
 	long long oct_clusters = 0, oct_groups = 0;
 	int oct_cluster_pitch = 0, oct_group_pitch = 0;
-	// scratch framebuffer for rt_render (host output)
+	// scratch framebuffer for rt_render (host output) and the compact shard of rt_render_multi
 	void* frame = nullptr;
 	size_t frame_bytes = 0;
-	void* pinned = nullptr;
-	size_t pinned_bytes = 0;
+	// rt_render_multi: the whole frame on devices[0], where the shards are gathered before the one D2H copy
+	void* gather = nullptr;
+	size_t gather_bytes = 0;
+	// rt_render_async: two device frames, a render and a copy stream, per slot "rendered" / "copied" events
+	void* aframe[2] = { nullptr, nullptr };
+	size_t aframe_bytes[2] = { 0, 0 };
+	hipStream_t render_stream = nullptr, copy_stream = nullptr;
+	hipEvent_t rendered[2] = { nullptr, nullptr }, copied[2] = { nullptr, nullptr };
+	long long ticket_of_slot[2] = { -1, -1 };
 };
 
 } // namespace rt
@@ -149,6 +161,9 @@ struct rt_scene {
 	unsigned long long generation = 1;
 	std::map<int, rt::DeviceState> dev;   // by HIP device ordinal
 	int first_device = -1;
+	int traversal = RT_TRAVERSAL_AUTO;    // rt_scene_set_traversal
+	int tiles_per_wave = 0;               // rt_scene_set_tiles_per_wave (0: the launcher's rule)
+	long long next_ticket = 0;            // rt_render_async
 };
 
 namespace rt {
@@ -167,7 +182,6 @@ float scene_box(const std::vector<float>& tris, float lo[3], float hi[3]);   // 
 
 // rt_kernels.hip
 DevScene dev_scene(const rt_scene* s, const DeviceState& d);
-extern int g_traversal_mode;     // rt_set_traversal
 bool use_packets(const DevScene& sc, const float trans16[16], int width, int height);   // the launcher's choice for an LBVH scene
 int launch_render(const DevScene& sc, const FrameParams& fp, int accel, int render_flags, bool count, hipStream_t stream);
 int launch_cast_rays(const DevScene& sc, int accel, int n, const float* d_rays7, float* d_out6, hipStream_t stream);

@@ -289,8 +289,11 @@ __device__ __forceinline__ Hit cast_ray_pruned(const DevScene& sc, c4ptr tri, in
 // farther inner child waits on a wave-uniform stack kept in the lanes of one VGPR.  No per-lane
 // stack, no sorting, no divergence, every load scalar.  The order of visits is not the index order,
 // so ties go to the lower index explicitly (as in rt_lbvh_trav.inl).
+// COUNT: the work counters of SURVEY 8d for the lanes whose ray is still searching (lim >= 0) — what
+// the walk costs each ray it carries, in the units the per-lane traversal counts for itself.
+template <bool COUNT>
 __device__ __forceinline__ void packet_leaf(c4ptr T, int i, vec3 o, vec3 d, int skip, bool first_only,
-                                            float eps_lo, Hit& h, float& lim, float& lim_hi, WaveProf& wp) {
+                                            float eps_lo, Hit& h, float& lim, float& lim_hi, LaneCounters& lc, WaveProf& wp) {
 	RT_PROF(wp, WP_TRI);
 	const float4 N4 = T[0], P14 = T[1];
 	const vec3 nn = xyz(N4), p1 = xyz(P14);
@@ -300,13 +303,16 @@ __device__ __forceinline__ void packet_leaf(c4ptr T, int i, vec3 o, vec3 d, int 
 	const float t = num / den;                                              // Source.cpp:383
 	const bool better = (t < lim) || (t == h.t && i < h.idx);               // Source.cpp:391 + index order
 	const bool cand = (t > RT_EPS_BELOW) && better;
+	if constexpr (COUNT) { const bool act = lim >= 0.0f && i != skip; lc.plane += act; lc.point += act && !(t < 0.0f); lc.edge += act && cand; }
 	if (__builtin_amdgcn_ballot_w64(cand) == 0) return;
 	RT_PROF(wp, WP_CAND);
 	const float4 P24 = T[2], P34 = T[3], E0 = T[4], E1 = T[5], E2 = T[6];   // the rest of the record in one go
 	const vec3 I = make3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);      // Source.cpp:389
 	const bool c0 = cand && (dot(nn, cross(xyz(E0), I - p1)) > 0.0f);       // Source.cpp:392
+	if constexpr (COUNT) lc.edge += c0 && i != skip;
 	if (__builtin_amdgcn_ballot_w64(c0) == 0) return;
 	const bool c1 = c0 && (dot(nn, cross(xyz(E1), I - xyz(P24))) > 0.0f);   // Source.cpp:393
+	if constexpr (COUNT) lc.edge += c1 && i != skip;
 	if (__builtin_amdgcn_ballot_w64(c1) == 0) return;
 	const bool c2 = c1 && (dot(nn, cross(xyz(E2), I - xyz(P34))) > 0.0f);   // Source.cpp:394
 	if (c2 && i != skip) {                                                  // Source.cpp:302, 396
@@ -316,8 +322,9 @@ __device__ __forceinline__ void packet_leaf(c4ptr T, int i, vec3 o, vec3 d, int 
 	}
 }
 
+template <bool COUNT>
 __device__ __forceinline__ Hit cast_ray_packet(const DevScene& sc, int oct, vec3 o, vec3 d, vec3 inv, vec3 oi,
-                                               int skip, float lim, bool first_only, WaveProf& wp) {
+                                               int skip, float lim, bool first_only, LaneCounters& lc, WaveProf& wp) {
 	Hit h;
 	h.t = 1e9f;
 	h.idx = -1;
@@ -341,8 +348,9 @@ __device__ __forceinline__ Hit cast_ray_packet(const DevScene& sc, int oct, vec3
 			const c4ptr R = hbox.offset_floats((long long)j * 8);
 			const float4 a0 = R[0], a1 = R[1];
 			RT_PROF(wp, WP_INBOX);
+			if constexpr (COUNT) lc.box += lim >= 0.0f;
 			if (__builtin_amdgcn_ballot_w64(slab_hit_oct(a0, a1, inv, oi, lim_hi)) != 0)
-				packet_leaf(hrec.offset_floats((long long)j * 32), __float_as_int(a1.w), o, d, skip, first_only, eps_lo, h, lim, lim_hi, wp);
+				packet_leaf<COUNT>(hrec.offset_floats((long long)j * 32), __float_as_int(a1.w), o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp);
 		}
 		if (__builtin_amdgcn_ballot_w64(lim >= 0.0f) == 0) return h;            // (shadow rays that all have their hit)
 	}
@@ -354,16 +362,18 @@ __device__ __forceinline__ Hit cast_ray_packet(const DevScene& sc, int oct, vec3
 		const float4 q0 = R[0], q1 = R[1], q2 = R[2], q3 = R[3];
 		const int refA = __float_as_int(q1.z), refB = __float_as_int(q1.w);
 		RT_PROF(wp, WP_GROUP);
+		if constexpr (COUNT) lc.box += lim >= 0.0f;
 		const bool hitA = __builtin_amdgcn_ballot_w64(slab_hit_oct(q0, q1, inv, oi, lim_hi)) != 0;
 		int next = -1;
 		if (hitA) {
-			if (refA < 0) packet_leaf(aos.offset_floats((long long)(~refA) * 32), ~refA, o, d, skip, first_only, eps_lo, h, lim, lim_hi, wp);
+			if (refA < 0) packet_leaf<COUNT>(aos.offset_floats((long long)(~refA) * 32), ~refA, o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp);
 			else next = refA;
 		}
 		// the farther child is tested after a near LEAF has had its chance to shorten the limits
+		if constexpr (COUNT) lc.box += lim >= 0.0f;
 		const bool hitB = __builtin_amdgcn_ballot_w64(slab_hit_oct(q2, q3, inv, oi, lim_hi)) != 0;
 		if (hitB) {
-			if (refB < 0) packet_leaf(aos.offset_floats((long long)(~refB) * 32), ~refB, o, d, skip, first_only, eps_lo, h, lim, lim_hi, wp);
+			if (refB < 0) packet_leaf<COUNT>(aos.offset_floats((long long)(~refB) * 32), ~refB, o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp);
 			else if (next >= 0) {
 				// v_writelane with a scalar value takes its lane index from m0 (one constant-bus operand); m0 is put back
 				int m0_saved;
@@ -570,7 +580,7 @@ __device__ __forceinline__ Hit trace(const DevScene& sc, const float4* lds_tri, 
 			const bool mine = live && lane_oct == oct;
 			todo &= ~__builtin_amdgcn_ballot_w64(mine);
 			RT_PROF(wp, WP_TRACE);
-			const Hit hp = cast_ray_packet(sc, (int)oct, o, d, inv, oi, skip, mine ? lim : -1.0f, shadow, wp);
+			const Hit hp = cast_ray_packet<COUNT>(sc, (int)oct, o, d, inv, oi, skip, mine ? lim : -1.0f, shadow, lc, wp);
 			if (mine) h = hp;
 		}
 		return h;
@@ -901,15 +911,20 @@ DevScene dev_scene(const rt_scene* s, const DeviceState& d) {
 	sc.hoist_count = d.hoist_count;
 	sc.far_guard = d.far_guard;
 	sc.packet_scale = d.packet_scale;
+	sc.traversal = s->traversal;
+	sc.per_lane_ok = d.per_lane_ok ? 1 : 0;
 	for (int k = 0; k < 3; k++) { sc.bb_lo[k] = d.bb_lo[k]; sc.bb_hi[k] = d.bb_hi[k]; }
 	return sc;
 }
 
 bool use_packets(const DevScene& sc, const float trans16[16], int width, int height) {
 	if (sc.skip_count <= 0) return false;
-	if (g_traversal_mode != RT_TRAVERSAL_AUTO) return g_traversal_mode == RT_TRAVERSAL_PACKET;
-	static const int env_packet = [] { const char* e = getenv("RT355_PACKET"); return e ? atoi(e) : -1; }();   // experiments
+	if (!sc.per_lane_ok) return true;        // the 4-wide tree is too deep for the per-lane stack (rt_lbvh.hip tree_depths)
+	if (sc.traversal != RT_TRAVERSAL_AUTO) return sc.traversal == RT_TRAVERSAL_PACKET;
+#ifdef RT_EXPERIMENT
+	static const int env_packet = [] { const char* e = getenv("RT355_PACKET"); return e ? atoi(e) : -1; }();
 	if (env_packet >= 0) return env_packet != 0;
+#endif
 	const float* m = trans16;
 	const float du = sqrtf(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]) / (float)(width > 0 ? width : 1);
 	const float dv = sqrtf(m[4] * m[4] + m[5] * m[5] + m[6] * m[6]) / (float)(height > 0 ? height : 1);
@@ -937,8 +952,12 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 	if (tiles * 64 > 0xf0000000LL) { set_error("rt_render: %dx%d needs more than 2^32 work items", fp.width, fp.local_rows); return RT_ERR_LIMIT; }
 	int tpw = fp.tiles_per_wave > 0 ? fp.tiles_per_wave : pick_tiles_per_wave(accel, tiles * n_frames);
 	const long long waves = (tiles + tpw - 1) / tpw;
+#ifdef RT_EXPERIMENT
 	static const int env_block = [] { const char* e = getenv("RT355_BLOCK_THREADS"); int v = e ? atoi(e) : 0; return (v == 64 || v == 128 || v == 256) ? v : 0; }();
 	const int threads = env_block ? env_block : 256;
+#else
+	const int threads = 256;
+#endif
 	const int wpb = threads / 64;
 	const long long blocks = (waves + wpb - 1) / wpb;
 	if (blocks * n_frames > 0x7fffffffLL) { set_error("rt_render: frame too large (%lld workgroups)", blocks * n_frames); return RT_ERR_LIMIT; }
@@ -957,8 +976,12 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 	// wide and very large frames do not gain (3200x1800 295 | 294, 3840x2160 387 | 397, 7680x4320 1364 | 1365:
 	// a band of full-width rows already spans most of the scene), hence the size limit.
 	fp.band_blocks = 0;
-	static const int env_bands = [] { const char* e = getenv("RT355_XCD_BANDS"); return e ? atoi(e) : -1; }();   // experiments: 0 off, 1 always
+#ifdef RT_EXPERIMENT
+	static const int env_bands = [] { const char* e = getenv("RT355_XCD_BANDS"); return e ? atoi(e) : -1; }();   // 0 off, 1 always
 	const bool bands = env_bands >= 0 ? env_bands != 0 : blocks <= 24000;
+#else
+	const bool bands = blocks <= 24000;
+#endif
 	if (accel == RT_ACCEL_LBVH && !count && n_frames >= 8 && bands) {
 		const long long band_blocks = (blocks + 7) / 8;
 		if (band_blocks * 8 * n_frames <= 0x7fffffffLL) {
@@ -968,7 +991,8 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 	}
 	if (accel == RT_ACCEL_LBVH) {
 		const size_t lds = (size_t)RT_STACK_LDS * RT_STACK_PITCH * sizeof(int);   // [entry][lane]
-		if (count) hipLaunchKernelGGL((render_kernel<2, true>), grid, block, lds, stream, sc_sel, fp, tpw);
+		if (count && sc_sel.skip_count > 0) hipLaunchKernelGGL((render_kernel<3, true>), grid, block, 0, stream, sc_sel, fp, tpw);   // the traversal the frame really gets
+		else if (count) hipLaunchKernelGGL((render_kernel<2, true>), grid, block, lds, stream, sc_sel, fp, tpw);
 		else if (sc_sel.skip_count > 0) hipLaunchKernelGGL((render_kernel<3, false>), grid, block, 0, stream, sc_sel, fp, tpw);
 		else hipLaunchKernelGGL((render_kernel<2, false>), grid, block, lds, stream, sc_sel, fp, tpw);
 	} else if (sc.n_tris <= RT_LDS_MAX_TRIS) {
@@ -989,7 +1013,7 @@ int launch_cast_rays(const DevScene& sc, int accel, int n, const float* d_rays7,
 	const dim3 grid((unsigned)((n + 255) / 256)), block(256);
 	if (accel == RT_ACCEL_LBVH) {
 		DevScene sc_sel = sc;
-		if (g_traversal_mode != RT_TRAVERSAL_PACKET) sc_sel.skip_count = 0;      // ray batches are per lane unless packets are forced
+		if (sc.traversal != RT_TRAVERSAL_PACKET && sc.per_lane_ok) sc_sel.skip_count = 0;   // ray batches are per lane unless packets are asked for
 		if (sc_sel.skip_count > 0) hipLaunchKernelGGL((cast_rays_kernel<3>), grid, block, 0, stream, sc_sel, n, d_rays7, d_out6);
 		else hipLaunchKernelGGL((cast_rays_kernel<2>), grid, block, (size_t)RT_STACK_LDS * 256 * sizeof(int), stream, sc_sel, n, d_rays7, d_out6);
 	} else if (sc.n_tris <= RT_LDS_MAX_TRIS) {

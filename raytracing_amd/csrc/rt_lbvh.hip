@@ -358,7 +358,9 @@ __global__ void __launch_bounds__(64) k_hoist(const float4* __restrict__ planes,
 void pick_hoisted(const std::vector<float>& tris, const float bb_lo[3], const float bb_hi[3], std::vector<int>& out) {
 	out.clear();
 	const int n = (int)(tris.size() / RT_TRI_FLOATS);
+#ifdef RT_EXPERIMENT
 	if (std::getenv("RT355_NO_HOIST")) return;
+#endif
 	const double ex = (double)bb_hi[0] - bb_lo[0], ey = (double)bb_hi[1] - bb_lo[1], ez = (double)bb_hi[2] - bb_lo[2];
 	const double scene_area = ex * ey + ey * ez + ez * ex;
 	if (!(scene_area > 0.0) || !(scene_area < 1e300)) return;
@@ -376,6 +378,28 @@ void pick_hoisted(const std::vector<float>& tris, const float bb_lo[3], const fl
 		}
 	}
 	if ((long long)out.size() * 4 > n || n - (int)out.size() < 2) out.clear();
+}
+
+// Depth of a tree given as `width` child references per node at `refs` (node 0 is the root; a
+// reference >= 0 and < n_nodes is an inner node, anything else a leaf or an empty slot): the number
+// of inner-node levels on the longest path.  Host side, at commit, from a copy of the references.
+int tree_depth(const std::vector<int>& refs, int width, int n_nodes) {
+	if (n_nodes <= 0) return 0;
+	std::vector<std::pair<int, int>> todo;
+	todo.emplace_back(0, 1);
+	int depth = 0;
+	size_t visited = 0;
+	while (!todo.empty()) {
+		const std::pair<int, int> cur = todo.back();
+		todo.pop_back();
+		if (++visited > (size_t)n_nodes) return -1;              // not a tree
+		if (cur.second > depth) depth = cur.second;
+		for (int c = 0; c < width; c++) {
+			const int r = refs[(size_t)cur.first * width + c];
+			if (r >= 0 && r < n_nodes) todo.emplace_back(r, cur.second + 1);
+		}
+	}
+	return depth;
 }
 
 template <typename T>
@@ -527,6 +551,32 @@ int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 		if (hoist) (void)hipFree(hoist);
 		return RT_ERR_DEVICE;
 	}
+	// Depths of the binary tree and of its 4-wide collapse, from host copies of the child references
+	// (16 B of every 64-byte node): what the traversal stacks have to hold (rt_lbvh_trav.inl header).
+	int depth2 = 0, depth4 = 0;
+	try {
+		std::vector<int> refs((size_t)(nt - 1) * 4);
+		LB_HIP(hipMemcpy2D(refs.data(), 16, (const char*)nodes + 48, 64, 16, (size_t)(nt - 1), hipMemcpyDeviceToHost));
+		for (size_t i = 0; i < (size_t)(nt - 1); i++) { refs[i * 2] = refs[i * 4]; refs[i * 2 + 1] = refs[i * 4 + 1]; }   // (left, right, 0, 0) -> pairs
+		depth2 = tree_depth(refs, 2, nt - 1);
+		LB_HIP(hipMemcpy2D(refs.data(), 16, (const char*)nodes4 + 16, 64, 16, (size_t)(nt - 1), hipMemcpyDeviceToHost));
+		for (int& r : refs) if (r == RT_BVH4_EMPTY) r = -1;
+		depth4 = tree_depth(refs, 4, nt - 1);
+	} catch (...) { set_error("LBVH: out of host memory measuring the tree"); rc = RT_ERR_NOMEM; }
+	if (rc == RT_OK && (depth2 < 1 || depth4 < 1 || depth2 > 63)) {
+		// (63-bit unique keys bound the Karras tree at 63 levels: the packet stack has 64 entries)
+		set_error("LBVH: malformed tree (binary depth %d, 4-wide depth %d)", depth2, depth4);
+		rc = RT_ERR_DEVICE;
+	}
+	if (rc != RT_OK) {
+		cleanup();
+		(void)hipFree(nodes);
+		(void)hipFree(nodes4);
+		(void)hipFree(aos);
+		if (pkt) (void)hipFree(pkt);
+		if (hoist) (void)hipFree(hoist);
+		return rc;
+	}
 #undef LB_TRY
 #undef LB_HIP
 	cleanup();
@@ -540,6 +590,9 @@ int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 	d.bvh_node_count = nt - 1;
 	d.hoisted = hoisted;
 	d.bvh_root = 0;
+	d.bvh_depth = depth2;
+	d.bvh4_depth = depth4;
+	d.per_lane_ok = 3 * depth4 <= RT_STACK_LIMIT;
 	d.build_ms = ms;
 	return RT_OK;
 }

@@ -13,14 +13,19 @@
 // tests, children visited nearest first.  A leaf test reads the triangle's AoS record in one burst.
 //
 // Per-lane traversal stack: RT_STACK_LDS entries in LDS (entry k of lane l at [k * blockDim + l]:
-// conflict-free), the rest — a Karras tree over 62 key bits is at most 62 deep — in a private
-// array that is only touched by unusually deep paths.
+// conflict-free), the rest in a private array that is only touched by unusually deep paths.  The
+// nearest-first walk of a 4-wide tree keeps up to 3 entries per level, so the stack needs
+// 3 * (depth of the 4-wide tree) entries in the worst case; lbvh_build measures that depth at
+// commit (rt_lbvh.hip tree_depths) and a tree with 3 * depth > RT_STACK_MAX is never handed to this
+// traversal (DevScene::per_lane_ok: the launchers walk it by packets, whose stack holds one entry
+// per binary level, at most 63).  The guards in push_any / pop_any keep the indices inside the
+// arrays regardless.
 #pragma once
 
 #ifndef RT_STACK_LDS
 #define RT_STACK_LDS 16      /* measured: 12-16 beats 24 and 32 (occupancy); deeper paths spill to a private array */
 #endif
-#define RT_STACK_MAX 64
+#define RT_STACK_MAX RT_STACK_LIMIT   /* include/rt355.h: 64 */
 #ifndef RT_LEAF_MIN
 #define RT_LEAF_MIN 1        /* lanes that must be waiting on a parked leaf before the wave makes a leaf trip */
 #endif
@@ -81,12 +86,12 @@ __device__ __forceinline__ Hit cast_ray_lbvh(const DevScene& sc, int* lds_stack,
 	auto pop_any = [&]() -> int {
 		if (sp == 0) return SENT;
 		sp--;
-		return sp < RT_STACK_LDS ? slot0[sp * RT_STACK_PITCH] : ovf[sp - RT_STACK_LDS];
+		return sp < RT_STACK_LDS ? slot0[sp * RT_STACK_PITCH] : ovf[min(sp, RT_STACK_MAX - 1) - RT_STACK_LDS];
 	};
 	auto push_any = [&](int v) {
 		if (sp < RT_STACK_LDS) slot0[sp * RT_STACK_PITCH] = v;
 		else if (sp < RT_STACK_MAX) ovf[sp - RT_STACK_LDS] = v;
-		sp++;
+		sp += sp < RT_STACK_MAX;          // (full: unreachable for the trees the launchers send here, see the header)
 	};
 
 	// pop for a wave whose lanes may or may not all be within the LDS part

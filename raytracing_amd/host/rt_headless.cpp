@@ -13,7 +13,7 @@
 // quad shows.  8-bit values use the GL unorm rule q = (int)(c*255.0f + 0.5f).
 //
 //   rt_headless [--scene stock|FILE] [--size W H] [--depth D] [--camera px py pz rx ry rz]
-//               [--frames N] [--fast] [--lbvh|--brute] [--device K]
+//               [--frames N] [--async] [--lbvh|--brute] [--device K]
 //               [--txt Image.txt] [--ppm out.ppm] [--raw out.f32] [--rto model.rto]
 //               [--walk SCRIPT]
 //
@@ -43,7 +43,7 @@ struct Options {
 	float cam[6] = { -5, 5, 5, 135, -45, 0 };   // Source.cpp:810
 	bool cam_set = false;
 	int frames = 1;
-	int mode = RT_RENDER_STRICT;
+	bool pipelined = false;     // --async: rt_render_async into two pinned frames (the hand-off of Source.cpp:1270 overlapped with the next render)
 	int accel = RT_ACCEL_AUTO;
 	int device = 0;
 	std::string txt, ppm, raw, rto, walk;
@@ -150,7 +150,7 @@ int main(int argc, char** argv) {
 		else if (a == "--depth") { need(1); o.depth = atoi(argv[++i]); o.depth_set = true; }
 		else if (a == "--camera") { need(6); for (int k = 0; k < 6; k++) o.cam[k] = strtof(argv[++i], nullptr); o.cam_set = true; }
 		else if (a == "--frames") { need(1); o.frames = atoi(argv[++i]); }
-		else if (a == "--fast") o.mode = RT_RENDER_FAST;
+		else if (a == "--async") o.pipelined = true;
 		else if (a == "--lbvh") o.accel = RT_ACCEL_LBVH;
 		else if (a == "--brute") o.accel = RT_ACCEL_BRUTE;
 		else if (a == "--device") { need(1); o.device = atoi(argv[++i]); }
@@ -161,10 +161,17 @@ int main(int argc, char** argv) {
 		else if (a == "--walk") { need(1); o.walk = argv[++i]; }
 		else { fprintf(stderr, "rt_headless: unknown option %s (see the header of rt_headless.cpp)\n", a.c_str()); return 2; }
 	}
+	auto bad_size = [](int w, int h) { return w <= 0 || h <= 0 || (long long)w * h > 0x7fffffffLL / 3; };
+	if (bad_size(o.width, o.height)) { fprintf(stderr, "rt_headless: frame size %dx%d is not usable (positive, width*height*3 < 2^31)\n", o.width, o.height); return 2; }
 	rt_scene* s = rt_scene_create();
 	if (!s) return fail("rt_scene_create");
 	int rc = (o.scene == "stock") ? build_stock(s) : build_from_file(s, o);
 	if (rc != 0) { fail("scene"); rt_scene_destroy(s); return 1; }
+	if (bad_size(o.width, o.height)) {      // (a `size` line of the scene file)
+		fprintf(stderr, "rt_headless: frame size %dx%d is not usable (positive, width*height*3 < 2^31)\n", o.width, o.height);
+		rt_scene_destroy(s);
+		return 2;
+	}
 	if (!o.rto.empty() && rt_scene_load_rto(s, o.rto.c_str()) < 0) { fail("loadModel"); rt_scene_destroy(s); return 1; }
 	if (rt_scene_commit(s, o.device, o.accel) != RT_OK) { fail("rt_scene_commit"); rt_scene_destroy(s); return 1; }
 
@@ -194,7 +201,18 @@ int main(int argc, char** argv) {
 	rt_camera camera;
 	rt_camera_init(&camera, o.cam, o.cam + 3);                          // Source.cpp:810
 	float trans[16];
-	std::vector<float> data((size_t)o.width * o.height * 3);            // Source.cpp:1035
+	const size_t n_floats = (size_t)o.width * o.height * 3;
+	std::vector<float> data;                                            // Source.cpp:1035
+	float* pinned[2] = { nullptr, nullptr };
+	try {
+		data.resize(n_floats);
+	} catch (...) { fprintf(stderr, "rt_headless: out of memory for a %dx%d frame\n", o.width, o.height); rt_scene_destroy(s); return 1; }
+	if (o.pipelined) {
+		pinned[0] = rt_frame_alloc(n_floats);
+		pinned[1] = rt_frame_alloc(n_floats);
+		if (!pinned[0] || !pinned[1]) { fail("rt_frame_alloc"); rt_frame_free(pinned[0]); rt_frame_free(pinned[1]); rt_scene_destroy(s); return 1; }
+	}
+	int ticket[2] = { -1, -1 };
 	float build_ms = 0;
 	rt_scene_build_ms(s, o.device, &build_ms);
 	printf("triangles %d lights %d accel %s build %.3f ms\n", rt_scene_triangle_count(s), rt_scene_light_count(s),
@@ -202,12 +220,24 @@ int main(int argc, char** argv) {
 	for (int f = 0; f < o.frames; f++) {
 		auto t0 = std::chrono::steady_clock::now();                     // Source.cpp:1129
 		rt_camera_trans(camera.rotations, trans);                       // Source.cpp:1145-1147
-		if (rt_render(s, camera.position, trans, o.width, o.height, o.depth, o.mode, data.data()) != RT_OK) { fail("rt_render"); rt_scene_destroy(s); return 1; }
+		if (o.pipelined) {
+			// frame f renders and copies while the caller still holds frame f-1 (what a viewer would be uploading)
+			ticket[f & 1] = rt_render_async(s, camera.position, trans, o.width, o.height, o.depth, RT_RENDER_STRICT, pinned[f & 1]);
+			if (ticket[f & 1] < 0) { fail("rt_render_async"); rt_scene_destroy(s); return 1; }
+			if (f > 0 && rt_render_wait(s, ticket[(f - 1) & 1]) != RT_OK) { fail("rt_render_wait"); rt_scene_destroy(s); return 1; }
+		} else if (rt_render(s, camera.position, trans, o.width, o.height, o.depth, RT_RENDER_STRICT, data.data()) != RT_OK) { fail("rt_render"); rt_scene_destroy(s); return 1; }
 		if (!keys.empty()) rt_camera_step(&camera, keys[f], key_ms[f]); // Source.cpp:1294-1295, 1307-1308 (scripted frame time)
 		auto t1 = std::chrono::steady_clock::now();
 		double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
 		printf("%f ms %f FPS\n", ms, 1000.0 / ms);                      // Source.cpp:1301
 	}
+	if (o.pipelined && o.frames > 0) {
+		const int last = (o.frames - 1) & 1;
+		if (rt_render_wait(s, ticket[last]) != RT_OK) { fail("rt_render_wait"); rt_scene_destroy(s); return 1; }
+		memcpy(data.data(), pinned[last], n_floats * sizeof(float));
+	}
+	rt_frame_free(pinned[0]);
+	rt_frame_free(pinned[1]);
 	if (!keys.empty())
 		printf("camera after the walk: position %.9g %.9g %.9g rotations %.9g %.9g %.9g\n", camera.position[0], camera.position[1],
 		       camera.position[2], camera.rotations[0], camera.rotations[1], camera.rotations[2]);

@@ -251,39 +251,8 @@ def spheres(n_spheres: int = 20, subdiv: int = 4, w: int = 800, h: int = 800,
     return sc.light((0, 8, 0), 4096)
 
 
-# ------------------------------------------------------------------------------------------
-# BASELINE config 5: deterministic camera path.
-# ------------------------------------------------------------------------------------------
-
-def camera_sweep(n_frames: int = 64, pos=(-5.0, 5.0, 5.0), rot=(135.0, -45.0, 0.0),
-                 nominal_ms: float = 16.0) -> List[Tuple[Tuple[float, ...], Tuple[float, ...]]]:
-    """Per frame: Camera::rotate(false,true,false,false) then translate(forward) with the speeds
-    the reference would have after a 16 ms frame (Source.cpp:108-112, 144-209, 1307-1308).
-    float32 arithmetic in the reference's order; returns [(pos, rot_deg)] for frames 0..n-1."""
-    f32 = np.float32
-    move_base = f32(1) / f32(128.0)                                   # Source.cpp:108
-    rot_base = f32(np.float64(move_base) * 3.14159265 * 2 * 2)        # Source.cpp:111 (double expr)
-    move_speed = f32(np.float64(move_base) * nominal_ms)              # Source.cpp:1307
-    rot_speed = f32(np.float64(rot_base) * nominal_ms)                # Source.cpp:1308
-    p = np.array(pos, dtype=f32)
-    r = np.array(rot, dtype=f32)
-    out = []
-    for _ in range(n_frames):
-        out.append((tuple(float(x) for x in p), tuple(float(x) for x in r)))
-        r = r.copy()
-        r[0] = f32(r[0] + rot_speed)                                  # Source.cpp:185-187
-        if np.float64(r[1]) > 89.99:                                  # Source.cpp:195-200
-            r[1] = f32(89.99)
-        if np.float64(r[1]) < -89.99:
-            r[1] = f32(-89.99)
-        rx = f32(r[0] * f32(0.01745329251994329576923690768489))
-        ry = f32(r[1] * f32(0.01745329251994329576923690768489))
-        d = np.array([f32(np.sin(rx)) * f32(np.cos(ry)), f32(np.sin(ry)),
-                      f32(np.cos(rx)) * f32(np.cos(ry))], dtype=f32)  # Source.cpp:202-206
-        inv = f32(1) / f32(np.sqrt(f32(f32(d[0] * d[0] + d[1] * d[1]) + d[2] * d[2])))
-        d = (d * inv).astype(f32)
-        p = (p + d * move_speed).astype(f32)                          # Source.cpp:170-172
-    return out
+# BASELINE config 5's deterministic camera path is walked by the reference's own controller:
+# api.camera_sweep (rt_camera_path).  Nothing is computed here.
 
 
 BUILTIN = {

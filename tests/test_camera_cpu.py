@@ -70,17 +70,21 @@ def test_path_records_the_pose_each_frame_is_drawn_with(golden):
     assert np.array_equal(_bits(cam.state()), _bits(golden["out"][-1, :17]))
 
 
-def test_numpy_sweep_follows_the_controller():
-    """scenes.camera_sweep (bench's 64-pose path) is look-right + forward at 16 ms in numpy float32.
-    numpy's float32 sin/cos are not glibc's sinf/cosf, so it follows the controller to a few ulp per
-    frame, not to the bit; the controller is the one pinned to the reference above."""
-    sweep = scenes.camera_sweep(64)
-    cam = api.Camera(sweep[0][0], sweep[0][1]).frame_time(16.0)
-    pos, tr = cam.path([api.KEY_LOOK_RIGHT | api.KEY_FORWARD] * 64, [16.0] * 64)
-    want_pos = np.array([p for p, _ in sweep], dtype=np.float32)
-    want_tr = np.array([api.camera_trans(r) for _, r in sweep], dtype=np.float32)
-    assert np.allclose(pos, want_pos, rtol=0, atol=2e-5)
-    assert np.allclose(tr, want_tr, rtol=0, atol=2e-5)
+def test_bench_sweep_is_the_pinned_controller(oracle):
+    """api.camera_sweep (the 64-pose path of bench.py and BASELINE config 5) is rt_camera_path with look
+    right + forward held down and 16 ms frames: the same bits as the oracle's restatement of the
+    reference's Camera, which the fixture above pins to the reference's own class."""
+    start = np.array([-5, 5, 5, 135, -45, 0], np.float32)
+    pos, tr = api.camera_sweep(64, start[:3], start[3:])
+    keys = np.zeros((64, 10), np.int32)
+    keys[:, 1] = 1          # look right
+    keys[:, 8] = 1          # move forward
+    out = oracle.camera_run(start, np.full(64, 16.0, np.float32), keys)
+    assert np.array_equal(_bits(pos[0]), _bits(start[:3]))
+    assert np.array_equal(_bits(tr[0]), _bits(oracle.camera_trans(start[3:])))
+    assert np.array_equal(_bits(pos[1:]), _bits(out[:-1, 0:3]))
+    assert np.array_equal(_bits(tr[1:]), _bits(out[:-1, 17:]))
+    assert len({tuple(p) for p in pos}) == 64 and not np.array_equal(tr[0], tr[63])
 
 
 def test_null_arguments_are_errors():

@@ -93,12 +93,10 @@ def test_scene_spanning_triangles_are_hoisted(oracle):
         _check_tree(sc.bvh(0), tris, h)
         want = oracle.render_desc(desc)
         for mode in (api.TRAVERSAL_PER_LANE, api.TRAVERSAL_PACKET):
-            api.set_traversal(mode)
-            try:
-                got = sc.render(desc.cam_pos, api.camera_trans(desc.cam_rot), desc.width, desc.height, desc.depth)
-            finally:
-                api.set_traversal(api.TRAVERSAL_AUTO)
+            sc.set_traversal(mode)
+            got = sc.render(desc.cam_pos, api.camera_trans(desc.cam_rot), desc.width, desc.height, desc.depth)
             assert np.array_equal(_bits(got), _bits(want))
+        sc.set_traversal(api.TRAVERSAL_AUTO)
         # rays that graze walls and spheres at equal t keep the lowest index
         rays = np.array([[0, 0, 0, 0, -1, 0, -1], [0, 0, 0, 1, 0, 0, -1], [0, 0, 0, 0, 1, 0, 3]], np.float32)
         sc.commit(0, api.ACCEL_BRUTE)
@@ -114,22 +112,17 @@ def test_frame_batches_through_the_tree_equal_single_frames():
     import torch
     for (w, h) in ((120, 88), (67, 45)):
         desc = scenes.spheres(3, 2, w, h, depth=2)
-        poses = scenes.camera_sweep(19, desc.cam_pos, desc.cam_rot)
-        cams = np.array([p for p, _ in poses], np.float32)
-        trs = np.stack([api.camera_trans(r) for _, r in poses])
+        cams, trs = api.camera_sweep(19, desc.cam_pos, desc.cam_rot)
         n = w * h * 3
         with api.Scene.from_desc(desc) as sc:
             sc.commit(0, api.ACCEL_LBVH)
             for mode in (api.TRAVERSAL_PER_LANE, api.TRAVERSAL_PACKET):
-                api.set_traversal(mode)
-                try:
-                    singles = [sc.render(cams[i], trs[i], w, h, desc.depth) for i in range(19)]
-                    buf = torch.full((19 * n,), -1.0, dtype=torch.float32, device="cuda:0")
-                    sc.render_frames_device(0, cams, trs, w, h, desc.depth, api.STRICT, buf.data_ptr(), n,
-                                            torch.cuda.current_stream().cuda_stream)
-                    torch.cuda.synchronize()
-                finally:
-                    api.set_traversal(api.TRAVERSAL_AUTO)
+                sc.set_traversal(mode)
+                singles = [sc.render(cams[i], trs[i], w, h, desc.depth) for i in range(19)]
+                buf = torch.full((19 * n,), -1.0, dtype=torch.float32, device="cuda:0")
+                sc.render_frames_device(0, cams, trs, w, h, desc.depth, api.STRICT, buf.data_ptr(), n,
+                                        torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
                 got = buf.cpu().numpy().reshape(19, h, w, 3)
                 for i in range(19):
                     assert np.array_equal(_bits(got[i]), _bits(singles[i])), (w, h, mode, i)
@@ -173,8 +166,9 @@ def test_golden_frames_through_the_tree(case):
     d = g["desc"]
     if d.n_triangles < 2:
         pytest.skip("a tree needs two leaves")
-    frame = api.render_desc(d, 0, api.ACCEL_AUTO if case == "degenerate_48" else api.ACCEL_LBVH)
-    assert hashlib.sha256(frame.tobytes()).hexdigest() == g["sha256"]
+    for traversal in (api.TRAVERSAL_PER_LANE, api.TRAVERSAL_PACKET):      # (degenerate_48: a NaN-normal leaf in both walks)
+        frame = api.render_desc(d, 0, api.ACCEL_LBVH, traversal=traversal)
+        assert hashlib.sha256(frame.tobytes()).hexdigest() == g["sha256"], traversal
 
 
 def test_cast_rays_known_answers_through_the_tree():
@@ -221,9 +215,174 @@ def test_lbvh_100k_rays_equal_brute():
 
 
 def test_auto_picks_lbvh_above_threshold():
-    with api.Scene.from_desc(scenes.spheres(4, 2, 8, 8)) as sc:       # 1292 triangles (> RT_BRUTE_AUTO_MAX = 1024)
+    with api.Scene.from_desc(scenes.spheres(4, 2, 8, 8)) as sc:       # 1292 triangles (> RT_BRUTE_AUTO_MAX = 128)
         sc.commit(0, api.ACCEL_AUTO)
         assert sc.accel(0) == api.ACCEL_LBVH
     with api.Scene.from_desc(scenes.stock(8, 8)) as sc:
         sc.commit(0, api.ACCEL_AUTO)
         assert sc.accel(0) == api.ACCEL_BRUTE
+
+
+# ---- deep trees: the traversal stacks -------------------------------------
+
+def _graded_chain(bits, per, dups=0, seed=0):
+    """Geometry graded towards a corner so that the Karras tree is a long chain: one cluster of `per`
+    nearly identical triangles per Morton bit b = 3*level + axis (box centre with only that bit set
+    among the leading ones), sizes halving with the level; `dups` exact copies of the innermost
+    triangle add index-bit levels below the chain.  Emulated on the CPU when the test was written:
+    (54, 3) -> binary depth 55, 4-wide depth 19; (51, 4, 256) -> 57 and 23."""
+    rng = np.random.default_rng(seed)
+    tris = []
+    for b in range(bits):
+        level, axis = divmod(b, 3)
+        cell = 2.0 ** -(level + 1)
+        c = np.full(3, 0.5 * cell)
+        c[axis] = 1.5 * cell
+        base = c + 0.45 * cell * rng.uniform(-1, 1, (3, 3))
+        for _ in range(per):
+            t = base + 1e-3 * cell * rng.normal(size=(3, 3))
+            t += c - 0.5 * (t.min(axis=0) + t.max(axis=0))           # the box centre decides the Morton code
+            tris.append(t)
+    tris += [tris[-1].copy() for _ in range(dups)]
+    desc = scenes.SceneDesc("graded_%d_%d_%d" % (bits, per, dups), width=96, height=64, depth=3,
+                            cam_pos=(1.2, 1.1, 1.3), cam_rot=(225.0, -35.26, 0.0))
+    rng2 = np.random.default_rng(seed + 1)
+    for t in np.asarray(tris, np.float32):
+        desc.tri(t[0], t[1], t[2], rng2.integers(30, 256, 3), 1.0 if rng2.random() < 0.2 else 0.0)
+    desc.light((1.5, 2.0, 0.5), 64.0)
+    desc.light((0.01, 0.3, 0.02), 1.0)
+    return desc, np.asarray(tris, np.float32)
+
+
+def _rays_into_the_corner(tris, n_random, seed):
+    """Rays from outside aimed at every cluster down to the innermost (they cross all the nested boxes
+    on the way), plus rays from the inside out and random ones."""
+    rng = np.random.default_rng(seed)
+    centres = tris.mean(axis=1)
+    rays = []
+    for c in centres[:: max(1, len(centres) // 400)]:
+        o = np.array([0.9, 1.0, 1.1]) + 0.05 * rng.normal(size=3)
+        rays.append([*o, *(c - o), -1.0])
+        rays.append([*(c * 0.5), *(rng.normal(size=3)), -1.0])
+    for _ in range(n_random):
+        o = rng.uniform(0, 1.2, 3) * 10.0 ** rng.uniform(-6, 0)
+        rays.append([*o, *rng.normal(size=3), float(rng.integers(-1, len(tris)))])
+    return np.asarray(rays, np.float32)
+
+
+def test_deep_tree_within_the_per_lane_stack(oracle):
+    """A 4-wide tree ~19 levels deep: the per-lane walk keeps up to 3 entries per level, far past the 16
+    entries it holds in LDS and close to the RT_STACK_LIMIT of 64.  Frames and ray batches by the
+    per-lane walk, by packets and by brute force are the oracle's."""
+    desc, tris = _graded_chain(54, 3)
+    rays = _rays_into_the_corner(tris, 1500, 3)
+    otris, _ = oracle.build_scene(desc)
+    want_rays = np.stack([oracle.cast_ray(otris, r[0:3], r[3:6], int(r[6])) for r in rays])
+    want = oracle.render_desc(desc, threads=4)
+    assert (want.max(axis=2) > 0).mean() > 0.05
+    with api.Scene.from_desc(desc) as sc:
+        sc.commit(0, api.ACCEL_LBVH)
+        d2, d4 = sc.bvh_depth(0)
+        assert 40 <= d2 <= 63 and 16 < 3 * d4 <= api.STACK_LIMIT, (d2, d4)
+        assert _check_tree(sc.bvh(0), sc.triangles(), sc.hoisted(0)) == d2
+        tr = api.camera_trans(desc.cam_rot)
+        for mode in (api.TRAVERSAL_PER_LANE, api.TRAVERSAL_PACKET):
+            sc.set_traversal(mode)
+            assert sc.traversal(0, tr, desc.width, desc.height) == mode
+            got = sc.render(desc.cam_pos, tr, desc.width, desc.height, desc.depth)
+            assert np.array_equal(_bits(got), _bits(want)), mode
+            out = sc.cast_rays(rays)
+            assert np.array_equal(out[:, :2], want_rays[:, :2]), mode
+            hit = want_rays[:, 0] > 0
+            assert np.array_equal(_bits(out[hit]), _bits(want_rays[hit])), mode
+        assert 0.2 < (want_rays[:, 0] > 0).mean() < 1.0
+
+
+def test_tree_too_deep_for_the_per_lane_stack_goes_by_packets(oracle):
+    """3 * (4-wide depth) > RT_STACK_LIMIT: the per-lane walk could overflow its stack, so the commit
+    marks the tree and every launch walks it by packets (one stack entry per binary level, at most
+    63) whatever traversal is asked for — results stay the oracle's, nothing is dropped silently."""
+    desc, tris = _graded_chain(51, 4, dups=256)
+    rays = _rays_into_the_corner(tris, 1500, 5)
+    otris, _ = oracle.build_scene(desc)
+    want_rays = np.stack([oracle.cast_ray(otris, r[0:3], r[3:6], int(r[6])) for r in rays])
+    want = oracle.render_desc(desc, threads=4)
+    with api.Scene.from_desc(desc) as sc:
+        sc.commit(0, api.ACCEL_LBVH)
+        d2, d4 = sc.bvh_depth(0)
+        assert d2 <= 63 and 3 * d4 > api.STACK_LIMIT, (d2, d4)
+        tr = api.camera_trans(desc.cam_rot)
+        for mode in (api.TRAVERSAL_AUTO, api.TRAVERSAL_PER_LANE, api.TRAVERSAL_PACKET):
+            sc.set_traversal(mode)
+            assert sc.traversal(0, tr, desc.width, desc.height) == api.TRAVERSAL_PACKET
+            got = sc.render(desc.cam_pos, tr, desc.width, desc.height, desc.depth)
+            assert np.array_equal(_bits(got), _bits(want)), mode
+            out = sc.cast_rays(rays)
+            assert np.array_equal(out[:, :2], want_rays[:, :2]), mode
+        sc.commit(0, api.ACCEL_BRUTE)
+        assert sc.bvh_depth(0) == (0, 0)
+        assert np.array_equal(_bits(sc.render(desc.cam_pos, tr, desc.width, desc.height, desc.depth)), _bits(want))
+
+
+def test_config4_full_size_all_traversals(oracle):
+    """BASELINE config 4 at full size — 102 412 triangles, 800x800: packets (with the walls hoisted and
+    the XCD band order of a frame batch) == per-lane walk == forced brute force, bit for bit, and a
+    64x64 frame of the same scene against the oracle (the reference's loop over 100k triangles)."""
+    import torch
+    desc = scenes.spheres(20, 4, 800, 800)
+    tr = api.camera_trans(desc.cam_rot)
+    with api.Scene.from_desc(desc) as sc:
+        assert sc.n_triangles == 102412
+        sc.commit(0, api.ACCEL_LBVH)
+        assert sc.hoisted(0).tolist() == list(range(12))
+        d2, d4 = sc.bvh_depth(0)
+        assert 3 * d4 <= api.STACK_LIMIT and d2 <= 63, (d2, d4)
+        frames = {}
+        for mode in (api.TRAVERSAL_PACKET, api.TRAVERSAL_PER_LANE):
+            sc.set_traversal(mode)
+            frames[mode] = sc.render(desc.cam_pos, tr, 800, 800, desc.depth)
+        assert np.array_equal(_bits(frames[api.TRAVERSAL_PACKET]), _bits(frames[api.TRAVERSAL_PER_LANE]))
+        # a batch of 8 equal poses runs in the band order: every copy is the single frame
+        sc.set_traversal(api.TRAVERSAL_PACKET)
+        n = 800 * 800 * 3
+        buf = torch.empty(8 * n, dtype=torch.float32, device="cuda:0")
+        sc.render_frames_device(0, np.tile(np.asarray(desc.cam_pos, np.float32), (8, 1)), np.tile(tr, (8, 1)), 800, 800, desc.depth,
+                                api.STRICT, buf.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        batch = buf.cpu().numpy().reshape(8, 800, 800, 3)
+        for k in (0, 3, 7):
+            assert np.array_equal(_bits(batch[k]), _bits(frames[api.TRAVERSAL_PACKET])), k
+        small = {}
+        for mode in (api.TRAVERSAL_PACKET, api.TRAVERSAL_PER_LANE):
+            sc.set_traversal(mode)
+            small[mode] = sc.render(desc.cam_pos, tr, 64, 64, desc.depth)
+        sc.commit(0, api.ACCEL_BRUTE)
+        brute = sc.render(desc.cam_pos, tr, 800, 800, desc.depth)
+        assert np.array_equal(_bits(brute), _bits(frames[api.TRAVERSAL_PACKET]))
+    want = oracle.render_desc(desc.with_size(64, 64), threads=16)
+    for mode, got in small.items():
+        assert np.array_equal(_bits(got), _bits(want)), mode
+    assert (brute.max(axis=2) > 0).mean() > 0.5
+
+
+def test_counting_kernel_follows_the_traversal_in_use():
+    """rt_render_stats on an LBVH scene counts inside the traversal the frame really gets (packets or
+    per lane): same frame bits, same ray and pixel counts from both, each with its own box/plane work."""
+    desc = scenes.spheres(6, 3, 320, 200, depth=2)
+    tr = api.camera_trans(desc.cam_rot)
+    with api.Scene.from_desc(desc) as sc:
+        sc.commit(0, api.ACCEL_LBVH)
+        plain = sc.render(desc.cam_pos, tr, desc.width, desc.height, desc.depth)
+        stats = {}
+        for mode in (api.TRAVERSAL_PER_LANE, api.TRAVERSAL_PACKET):
+            sc.set_traversal(mode)
+            frame, st = sc.render_stats(desc.cam_pos, tr, desc.width, desc.height, desc.depth)
+            assert np.array_equal(_bits(frame), _bits(plain)), mode
+            stats[mode] = st.as_dict()
+    a, b = stats[api.TRAVERSAL_PER_LANE], stats[api.TRAVERSAL_PACKET]
+    for k in ("rays_primary", "rays_bounce", "rays_shadow", "px_hit", "px_mirror", "px_lit"):
+        assert a[k] == b[k] > 0, k
+    assert a["rays_primary"] == desc.width * desc.height
+    for k in ("n_box", "n_plane", "n_point", "n_edge"):
+        assert a[k] > 0 and b[k] > 0, k
+    assert b["n_box"] != a["n_box"]                   # a wave's walk visits the union of its rays' boxes
