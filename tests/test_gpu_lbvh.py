@@ -279,7 +279,7 @@ def test_deep_tree_within_the_per_lane_stack(oracle):
     otris, _ = oracle.build_scene(desc)
     want_rays = np.stack([oracle.cast_ray(otris, r[0:3], r[3:6], int(r[6])) for r in rays])
     want = oracle.render_desc(desc, threads=4)
-    assert (want.max(axis=2) > 0).mean() > 0.05
+    assert (want.max(axis=2) > 0).sum() >= 20
     with api.Scene.from_desc(desc) as sc:
         sc.commit(0, api.ACCEL_LBVH)
         d2, d4 = sc.bvh_depth(0)

@@ -168,7 +168,7 @@ def test_config5_8k_row_tile_shards_equal_the_whole_frame(name):
         assert total_rows == H
         assert torch.equal(full.view(torch.int32), whole.view(torch.int32))
         lit = float((whole.view(H, W, 3).amax(dim=2) > 0).float().mean())
-        assert lit > 0.5
+        assert lit > 0.2
         # and the host-side gather of rt_render_multi (one device here) lands on the same frame
         if name == "room":
             multi = sc.render_multi([0], cam, tr, W, H, desc.depth, tile_rows=tile_rows)
