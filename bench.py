@@ -73,6 +73,7 @@ def parse():
     ap.add_argument("--frames-per-launch", type=int, default=0, help="frames per launch (= per step); 0: the workload's own (32; 8 at 8K)")
     ap.add_argument("--size", type=int, nargs=2, default=None, help="override the workload's frame size (experiments)")
     ap.add_argument("--traversal", default="auto", choices=["auto", "per-lane", "packet"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "state-machine", "lockstep"], help="form of the brute-force render kernel (rt_scene_set_kernel)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo lets several ranks share one GPU to rehearse the N>1 path")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -149,6 +150,7 @@ class Workload:
         self.W, self.H, self.D = desc.width, desc.height, desc.depth
         self.scene = api.Scene.from_desc(desc)
         self.scene.set_traversal({"auto": api.TRAVERSAL_AUTO, "per-lane": api.TRAVERSAL_PER_LANE, "packet": api.TRAVERSAL_PACKET}[args.traversal])
+        self.scene.set_kernel({"auto": api.KERNEL_AUTO, "state-machine": api.KERNEL_STATE_MACHINE, "lockstep": api.KERNEL_LOCKSTEP}[args.kernel])
         if args.tiles_per_wave:
             self.scene.set_tiles_per_wave(args.tiles_per_wave)
         self.scene.commit(dev, api.ACCEL_LBVH if accel_name == "lbvh" else api.ACCEL_BRUTE)

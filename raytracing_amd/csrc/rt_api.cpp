@@ -105,7 +105,31 @@ DeviceState* committed(const char* fn, rt_scene* s, int device) {
 	return &it->second;
 }
 
-void fill_frame(FrameParams& fp, const float cam[3], const float trans16[16], int w, int h, int depth) {
+// Source.cpp:534-535 for one dimension of n pixels: is the division-free form of FrameParams::rcp_w the
+// IEEE quotient, bit for bit, for every numerator the frame has?
+bool uv_division_free(int n) {
+	if (n <= 0 || n >= (1 << 22)) return false;
+	const float fn = (float)n, half = fn * 0.5f, c = 1.0f / fn;
+	for (int x = 0; x < n; x++) {
+		const float num = (float)x - half;
+		const float want = num / fn;
+		const float q = num * c;
+		const float r = fmaf(-q, fn, num);
+		const float got = fmaf(r, c, q);
+		if (memcmp(&want, &got, sizeof want) != 0) return false;
+	}
+	return true;
+}
+
+void fill_frame(rt_scene* s, FrameParams& fp, const float cam[3], const float trans16[16], int w, int h, int depth) {
+	if (s->uv_w != w || s->uv_h != h) {          // checked once per frame size and scene
+		s->uv_fast = uv_division_free(w) && uv_division_free(h);
+		s->uv_w = w;
+		s->uv_h = h;
+	}
+	fp.rcp_w = 1.0f / (float)w;
+	fp.rcp_h = 1.0f / (float)h;
+	fp.uv_fast = s->uv_fast ? 1 : 0;
 	memset(fp.cam, 0, sizeof fp.cam);
 	memset(fp.m, 0, sizeof fp.m);
 	memcpy(fp.cam[0], cam, 3 * sizeof(float));
@@ -210,6 +234,13 @@ int rt_scene_set_tiles_per_wave(rt_scene* s, int tiles) {
 	if (!s) { set_error("rt_scene_set_tiles_per_wave: NULL scene"); return RT_ERR_INVALID; }
 	if (tiles < 0 || tiles > RT_TILES_PER_WAVE_MAX) { set_error("rt_scene_set_tiles_per_wave: %d is outside [0, %d]", tiles, RT_TILES_PER_WAVE_MAX); return RT_ERR_INVALID; }
 	s->tiles_per_wave = tiles;
+	return RT_OK;
+}
+
+int rt_scene_set_kernel(rt_scene* s, int kind) {
+	if (!s) { set_error("rt_scene_set_kernel: NULL scene"); return RT_ERR_INVALID; }
+	if (kind < RT_KERNEL_AUTO || kind > RT_KERNEL_LOCKSTEP) { set_error("rt_scene_set_kernel: unknown kind %d", kind); return RT_ERR_INVALID; }
+	s->kernel_kind = kind;
 	return RT_OK;
 }
 
@@ -350,7 +381,7 @@ int rt_render_tiles_device(rt_scene* s, int device, const float cam_pos[3], cons
 	DeviceState* d = committed("rt_render_tiles_device", s, device);
 	if (!d) return RT_ERR_STATE;
 	FrameParams fp;
-	fill_frame(fp, cam_pos, trans16, width, height, max_bounces);
+	fill_frame(s, fp, cam_pos, trans16, width, height, max_bounces);
 	fp.tile_rows = tile_rows;
 	fp.tile_first = tile_first;
 	fp.tile_stride = tile_stride;
@@ -378,7 +409,7 @@ int rt_render_frames_device(rt_scene* s, int device, int n_frames, const float* 
 	for (int f0 = 0; f0 < n_frames; f0 += RT_MAX_FRAMES) {
 		const int nf = n_frames - f0 < RT_MAX_FRAMES ? n_frames - f0 : RT_MAX_FRAMES;
 		FrameParams fp;
-		fill_frame(fp, cam_pos3 + 3 * (size_t)f0, trans16 + 16 * (size_t)f0, width, height, max_bounces);
+		fill_frame(s, fp, cam_pos3 + 3 * (size_t)f0, trans16 + 16 * (size_t)f0, width, height, max_bounces);
 		for (int k = 0; k < nf; k++) {
 			memcpy(fp.cam[k], cam_pos3 + 3 * (size_t)(f0 + k), 3 * sizeof(float));
 			memcpy(fp.m[k], trans16 + 16 * (size_t)(f0 + k), 16 * sizeof(float));
@@ -448,7 +479,7 @@ int rt_render_stats(rt_scene* s, const float cam_pos[3], const float trans16[16]
 	if (rc != RT_OK) return rc;
 	RT_HIP(hipMemsetAsync(d->counters, 0, 32 * sizeof(unsigned long long), nullptr));
 	FrameParams fp;
-	fill_frame(fp, cam_pos, trans16, width, height, max_bounces);
+	fill_frame(s, fp, cam_pos, trans16, width, height, max_bounces);
 	fp.tiles_per_wave = s->tiles_per_wave;
 	fp.out = (float*)d->frame;
 	fp.counters = (unsigned long long*)d->counters;

@@ -26,8 +26,9 @@ namespace rt {
 //   plane 8  GHI[g] = upper corner            (an empty group has GLO = +inf, GHI = -inf)
 //   plane 9  CLO[c] = (lower corner of cluster c, first group as int bits)   clusters = runs of
 //   plane 10 CHI[c] = (upper corner,              group count as int bits)   consecutive groups
+//   plane 11 COL = (color.r, color.g, color.b, shininess): what shading reads by hit index, in one load
 // The `p` field of the reference record (Source.cpp:33, always == p1) is not uploaded.
-enum { PL_N = 0, PL_P1, PL_P2, PL_P3, PL_E0, PL_E1, PL_E2, PL_GLO, PL_GHI, PL_CLO, PL_CHI, PL_COUNT };
+enum { PL_N = 0, PL_P1, PL_P2, PL_P3, PL_E0, PL_E1, PL_E2, PL_GLO, PL_GHI, PL_CLO, PL_CHI, PL_COL, PL_COUNT };
 #define RT_CLUSTER_MAX_GROUPS 16
 #define RT_BVH4_EMPTY 0x7ffffffe     /* unused child slot of a 4-wide node */
 #ifndef RT_GROUP
@@ -77,6 +78,7 @@ struct DevScene {
 	float far_guard;        // |origin| beyond this: the box tests are switched off for the ray
 	float packet_scale;     // scene diagonal / mean triangle box diagonal (launcher: is an 8x8 tile of rays coherent?)
 	int traversal;          // rt_scene_set_traversal: RT_TRAVERSAL_AUTO | _PER_LANE | _PACKET (host side only)
+	int kernel_kind;        // rt_scene_set_kernel (host side only)
 	int per_lane_ok;        // 0: the 4-wide tree is too deep for the per-lane stack (RT_STACK_MAX); packets only
 };
 
@@ -104,6 +106,12 @@ struct FrameParams {
 	int tile_rows, tile_first, tile_stride;
 	int local_rows;         // rows this launch renders
 	int tiles_per_wave;     // 8x8 pixel tiles per wavefront, 0 = let the launcher choose
+	// u = (x - w/2) / w and v = (y - h/2) / h (Source.cpp:534-535) without the division sequence: with
+	// rcp_w = RN(1/w), q = n * rcp_w, r = fma(-q, w, n), u = fma(r, rcp_w, q) is the correctly rounded
+	// quotient for almost every numerator; the launcher checks EVERY column and row of the frame on the
+	// host against the IEEE division and sets uv_fast only when all of them agree bit for bit.
+	float rcp_w, rcp_h;
+	int uv_fast;
 	float* out;             // local_rows * width * 3 floats
 	unsigned long long* counters;   // rt_stats as 10 x u64, or null
 };
@@ -164,6 +172,9 @@ struct rt_scene {
 	int traversal = RT_TRAVERSAL_AUTO;    // rt_scene_set_traversal
 	int tiles_per_wave = 0;               // rt_scene_set_tiles_per_wave (0: the launcher's rule)
 	long long next_ticket = 0;            // rt_render_async
+	int kernel_kind = RT_KERNEL_AUTO;     // rt_scene_set_kernel
+	int uv_w = -1, uv_h = -1;             // frame size the division-free u, v were last checked for (rt_api.cpp fill_frame)
+	bool uv_fast = false;
 };
 
 namespace rt {

@@ -503,7 +503,15 @@ __device__ __forceinline__ vec3 primary_dir(int x, int y, const FrameParams& fp,
 	// binary64 quotient of binary32 operands to binary32 equals the correctly rounded binary32
 	// quotient (53 >= 2*24 + 2), so one IEEE binary32 division gives the same bits.
 	float u, v;
-	if (fp.width < (1 << 22) && fp.height < (1 << 22)) {
+	if (fp.uv_fast) {
+		// the same quotients without the division sequence (FrameParams::rcp_w; the launcher checked every
+		// column and row of this frame size against the IEEE division, bit for bit)
+		const float hf = (float)fp.height, wf = (float)fp.width;
+		const float nv = (float)y - hf * 0.5f, nu = (float)x - wf * 0.5f;
+		const float qv = nv * fp.rcp_h, qu = nu * fp.rcp_w;
+		v = __builtin_fmaf(__builtin_fmaf(-qv, hf, nv), fp.rcp_h, qv);
+		u = __builtin_fmaf(__builtin_fmaf(-qu, wf, nu), fp.rcp_w, qu);
+	} else if (fp.width < (1 << 22) && fp.height < (1 << 22)) {
 		v = ((float)y - (float)fp.height * 0.5f) / (float)fp.height;
 		u = ((float)x - (float)fp.width * 0.5f) / (float)fp.width;
 	} else {
@@ -624,6 +632,39 @@ __device__ __forceinline__ Hit trace(const DevScene& sc, const float4* lds_tri, 
 			return cast_ray_pruned<false, false>(sc, tri, 0, nullptr, o, d, inv, oi, skip, lim, shadow, wp);
 		}
 	}
+}
+
+// castRay by brute force for ONE kind of ray (the lockstep kernel below knows at every call site whether
+// its rays are primary, bounce or shadow rays, so each site carries only the variants it can need).
+enum { RAY_PRIMARY = 0, RAY_BOUNCE = 1, RAY_SHADOW = 2 };
+template <int ACCEL, int KIND>
+__device__ __forceinline__ Hit trace_brute(const DevScene& sc, const float* lds_num0, vec3 o, vec3 d, int skip, bool live, float dist, WaveProf& wp) {
+	static_assert(ACCEL == 0 || ACCEL == 1, "brute force only");
+	// (the comments of trace<> above apply word for word: clamped direction, exit bound, far_guard, octant)
+	const vec3 ds = make3(fabsf(d.x) < 1e-30f ? 1e-30f : d.x, fabsf(d.y) < 1e-30f ? 1e-30f : d.y, fabsf(d.z) < 1e-30f ? 1e-30f : d.z);
+	const bool near = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) < sc.far_guard;
+	vec3 inv = make3(__builtin_amdgcn_rcpf(ds.x), __builtin_amdgcn_rcpf(ds.y), __builtin_amdgcn_rcpf(ds.z));
+	vec3 oi = make3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
+	const float ex = fminf(fminf(fmaxf(__builtin_fmaf(sc.bb_lo[0], inv.x, oi.x), __builtin_fmaf(sc.bb_hi[0], inv.x, oi.x)),
+	                             fmaxf(__builtin_fmaf(sc.bb_lo[1], inv.y, oi.y), __builtin_fmaf(sc.bb_hi[1], inv.y, oi.y))),
+	                       fmaxf(__builtin_fmaf(sc.bb_lo[2], inv.z, oi.z), __builtin_fmaf(sc.bb_hi[2], inv.z, oi.z)));
+	float lim = near ? fminf(ex + fabsf(ex) * 1e-4f, 1e9f) : 1e9f;       // 1e9: Source.cpp:278
+	if constexpr (KIND == RAY_SHADOW) lim = fminf(lim, __uint_as_float(__float_as_uint(dist) + 1u));   // first float > dist (Source.cpp:476)
+	lim = fminf(lim, 1e9f);
+	if (!live) lim = -1.0f;
+	if (!near) { inv = make3(0.f, 0.f, 0.f); oi = make3(0.f, 0.f, 0.f); }
+	const unsigned int lane_oct = (__float_as_uint(ds.x) >> 31) | ((__float_as_uint(ds.y) >> 31) << 1) | ((__float_as_uint(ds.z) >> 31) << 2);
+	const unsigned long long lv = __builtin_amdgcn_ballot_w64(live);
+	const int oct = (int)__builtin_amdgcn_readlane(lane_oct, lv ? __builtin_ctzll(lv) : 0);
+	const bool oct_uniform = __builtin_amdgcn_ballot_w64(live && (lane_oct != (unsigned int)oct || !near)) == 0ull;
+	c4ptr tri;
+	tri.p = (const __attribute__((address_space(4))) v4f*)(unsigned long long)sc.planes;
+	constexpr bool first_only = KIND == RAY_SHADOW;
+	if (oct_uniform) {
+		if constexpr (KIND == RAY_PRIMARY && ACCEL == 0) return cast_ray_pruned<true, true>(sc, tri, oct, lds_num0, o, d, inv, oi, skip, lim, false, wp);
+		else return cast_ray_pruned<false, true>(sc, tri, oct, lds_num0, o, d, inv, oi, skip, lim, first_only, wp);
+	}
+	return cast_ray_pruned<false, false>(sc, tri, 0, lds_num0, o, d, inv, oi, skip, lim, first_only, wp);
 }
 
 // Per-lane attribute fetch by hit index (shininess Source.cpp:570/575, normal :561, colour :489).
@@ -861,6 +902,129 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 	}
 }
 
+// ---- the render kernel in lockstep form (brute force, shallow bounce depth) ------------------------
+// The state machine above exists for divergence in bounce depth: any lane may be at any stage, so every
+// pass of its loop runs the whole stage-transition and shading code.  With the reference's depth
+// (maxBounces = 1, Source.cpp:567) a pixel takes a primary ray, at most two mirror rays and one shadow
+// ray per light, and the pixels of an 8x8 tile nearly always take the SAME path (a wall is a mirror or
+// it is not).  Here a wavefront walks its tiles one after the other and all 64 lanes stay in step:
+// primary castRay -> (only if some lane hit a mirror) the bounce loop of Source.cpp:572-580 on those
+// lanes -> per light one shadow castRay and the accumulation of Source.cpp:476-489 -> store.  Every call
+// site knows its kind of ray (trace_brute<KIND>), the lights are wave-uniform (scalar loads), colour and
+// shininess come in one load (plane COL), and nothing is re-decided per pass: about 40 % fewer vector
+// instructions per pixel than the state machine on the room scene.  Same arithmetic, same bits.
+#ifndef RT_LOCKSTEP_TILES
+#define RT_LOCKSTEP_TILES 4
+#endif
+#ifndef RT_LOCKSTEP_MAX_BOUNCES
+#define RT_LOCKSTEP_MAX_BOUNCES 2     /* deeper bounce loops go to the state machine, which refills idle lanes */
+#endif
+template <int ACCEL>
+__global__ void __launch_bounds__(256, RT_MIN_WAVES) render_lockstep_kernel(DevScene sc, FrameParams fp, int tiles_per_wave) {
+	extern __shared__ float4 s_tri[];
+	float* s_num0 = (float*)s_tri;
+	const int frame = fp.n_frames > 1 ? (int)(blockIdx.x / fp.blocks_per_frame) : 0;      // workgroup-uniform
+	const unsigned int block_in_frame = blockIdx.x - (unsigned int)frame * fp.blocks_per_frame;
+	const vec3 cam = make3(fp.cam[frame][0], fp.cam[frame][1], fp.cam[frame][2]);
+	if constexpr (ACCEL == 0) {
+		// numerator of Source.cpp:383 for rays that start at the camera (see render_kernel)
+		const int lds_stride = lds_stride_of(sc.n_tris);
+		for (int i = threadIdx.x; i < lds_stride; i += blockDim.x)
+			s_num0[i] = dot(xyz(sc.planes[PL_P1 * sc.stride + i]) - cam, xyz(sc.planes[PL_N * sc.stride + i]));
+		__syncthreads();
+	}
+	const int tiles_x = (fp.width + RT_TILE_W - 1) / RT_TILE_W;
+	const int tiles_y = (fp.local_rows + RT_TILE_H - 1) / RT_TILE_H;
+	const unsigned int n_tiles = (unsigned int)tiles_x * (unsigned int)tiles_y;
+	const unsigned int wave = __builtin_amdgcn_readfirstlane(block_in_frame * (blockDim.x >> 6) + (threadIdx.x >> 6));
+	unsigned int tile = wave * (unsigned int)tiles_per_wave;          // (tiles_per_wave <= 1024 and wave < 2^21: no wrap)
+	unsigned int tile_end = tile + (unsigned int)tiles_per_wave;
+	if (tile_end > n_tiles) tile_end = n_tiles;
+	if (tile >= tile_end) return;
+	int ty = (int)(tile / (unsigned int)tiles_x), tx = (int)(tile - (unsigned int)ty * (unsigned int)tiles_x);
+	const int lx = (int)(threadIdx.x & (RT_TILE_W - 1)), lyi = (int)((threadIdx.x & 63u) / RT_TILE_W);
+	c4ptr lights;
+	lights.p = (const __attribute__((address_space(4))) v4f*)(unsigned long long)sc.lights;
+	WaveProf wp = {};
+	for (; tile < tile_end; tile++) {
+		const int x = tx * RT_TILE_W + lx, ly = ty * RT_TILE_H + lyi;
+		const bool inside = (x < fp.width) && (ly < fp.local_rows);
+		if (++tx == tiles_x) { tx = 0; ty++; }
+		// ---- primary ray (Source.cpp:534-548)
+		const vec3 d = primary_dir(x, global_row(ly, fp), fp, frame);
+		const Hit h = trace_brute<ACCEL, RAY_PRIMARY>(sc, s_num0, cam, d, -1, inside, 0.f, wp);
+		const bool hit = inside && h.idx >= 0;
+		float4 A = make_float4(0.f, 0.f, 0.f, 0.f);                          // colour, shininess of the triangle to be lit
+		if (hit) A = sc.planes[PL_COL * sc.stride + h.idx];
+		bool bouncing = hit && A.w > 0.5f;                                   // Source.cpp:570
+		bool shade = hit && !bouncing;                                       // Source.cpp:597
+		vec3 hp = h.p;                                                       // what processLighting gets: hit.point, hit.cur
+		int hidx = h.idx;
+		float dim = 1.0f;
+		// ---- mirrors: Source.cpp:561, 570-594 (skipped by the whole wave when no lane hit one)
+		if (__builtin_amdgcn_ballot_w64(bouncing) != 0ull) {
+			vec3 bo = h.p, bd = d;
+			int bskip = h.idx, bounces = 0;
+			{
+				float4 N4 = make_float4(0.f, 0.f, 0.f, 0.f);
+				if (bouncing) N4 = sc.planes[PL_N * sc.stride + h.idx];
+				bd = normalize(reflect(d, face_normal(d, xyz(N4))));         // Source.cpp:561, 572
+			}
+			while (__builtin_amdgcn_ballot_w64(bouncing) != 0ull) {
+				const Hit g = trace_brute<ACCEL, RAY_BOUNCE>(sc, s_num0, bo, bd, bskip, bouncing, 0.f, wp);   // Source.cpp:573, 578
+				const bool ghit = bouncing && g.idx >= 0;
+				float4 GA = make_float4(0.f, 0.f, 0.f, 0.f);
+				if (ghit) GA = sc.planes[PL_COL * sc.stride + g.idx];
+				const bool cont = ghit && bounces < fp.max_bounces && GA.w > 0.5f;   // Source.cpp:575
+				if (ghit && !cont) {                                         // Source.cpp:582-586
+					hp = g.p; hidx = g.idx; A = GA;
+					dim = (float)(bounces * 1);
+					shade = true;
+				}                                                            // (a miss stays unlit: Source.cpp:590)
+				if (__builtin_amdgcn_ballot_w64(cont) != 0ull) {
+					float4 N4 = make_float4(0.f, 0.f, 0.f, 0.f);
+					if (cont) N4 = sc.planes[PL_N * sc.stride + g.idx];
+					if (cont) {                                              // Source.cpp:576-579
+						bd = normalize(reflect(bd, face_normal(bd, xyz(N4))));
+						bo = g.p;
+						bskip = g.idx;
+						bounces++;
+					}
+				}
+				bouncing = cont;
+			}
+		}
+		// ---- processLighting (Source.cpp:460-494), one light at a time for the whole wave
+		vec3 color = make3(0.f, 0.f, 0.f);                                   // Source.cpp:462
+		if (__builtin_amdgcn_ballot_w64(shade) != 0ull) {
+			for (int li = 0; li < sc.n_lights; li++) {
+				const float4 L = lights[li];
+				const vec3 ray = make3(L.x - hp.x, L.y - hp.y, L.z - hp.z);  // Source.cpp:470
+				const float s = sqrtf(dot(ray, ray));                        // magnitude(ray), Source.cpp:26-28
+				const float inv = 1.0f / s;                                  // glm::normalize: v * inversesqrt(dot(v,v))
+				const vec3 ld = ray * inv;
+				const Hit sh = trace_brute<ACCEL, RAY_SHADOW>(sc, s_num0, hp, ld, hidx, shade, s, wp);   // Source.cpp:473
+				if (shade && (!(sh.idx >= 0) || sh.t > s)) {                 // Source.cpp:476
+					const float f = 1.0f / (s * s) * L.w;                    // Source.cpp:488
+					const float modify = (float)div255(div255((double)f));   // ... / 255.0 / 255.0f, in double
+					color.x = color.x + modify * A.x;                        // Source.cpp:489
+					color.y = color.y + modify * A.y;
+					color.z = color.z + modify * A.z;
+				}
+			}
+		}
+		if (inside) {
+			vec3 c = color;
+			c.x = c.x * dim; c.y = c.y * dim; c.z = c.z * dim;               // Source.cpp:586; dim == 1 (exact) on the matte and miss paths
+			if (c.x > 1.0f) c.x = 1.0f;                                      // Source.cpp:602-610
+			if (c.y > 1.0f) c.y = 1.0f;
+			if (c.z > 1.0f) c.z = 1.0f;
+			float* out = fp.out + (long long)frame * fp.frame_stride + (ly * fp.width + x) * 3;   // Source.cpp:550 (local rows)
+			out[0] = c.x; out[1] = c.y; out[2] = c.z;                        // Source.cpp:612-614
+		}
+	}
+}
+
 // ---- castRay for a batch of rays (tests, tools) ----------------------------------------------
 template <int ACCEL>
 __global__ void __launch_bounds__(256) cast_rays_kernel(DevScene sc, int n, const float* __restrict__ rays7, float* __restrict__ out6) {
@@ -912,6 +1076,7 @@ DevScene dev_scene(const rt_scene* s, const DeviceState& d) {
 	sc.far_guard = d.far_guard;
 	sc.packet_scale = d.packet_scale;
 	sc.traversal = s->traversal;
+	sc.kernel_kind = s->kernel_kind;
 	sc.per_lane_ok = d.per_lane_ok ? 1 : 0;
 	for (int k = 0; k < 3; k++) { sc.bb_lo[k] = d.bb_lo[k]; sc.bb_hi[k] = d.bb_hi[k]; }
 	return sc;
@@ -950,7 +1115,12 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 	const int n_frames = fp.n_frames < 1 ? 1 : fp.n_frames;
 	const long long tiles = (long long)((fp.width + RT_TILE_W - 1) / RT_TILE_W) * ((fp.local_rows + RT_TILE_H - 1) / RT_TILE_H);
 	if (tiles * 64 > 0xf0000000LL) { set_error("rt_render: %dx%d needs more than 2^32 work items", fp.width, fp.local_rows); return RT_ERR_LIMIT; }
-	int tpw = fp.tiles_per_wave > 0 ? fp.tiles_per_wave : pick_tiles_per_wave(accel, tiles * n_frames);
+	// brute force at the reference's bounce depth: the lockstep kernel (its tiles are walked one after the
+	// other, so longer runs only amortise the per-workgroup set-up; measured best at 4)
+	const bool lockstep = accel != RT_ACCEL_LBVH && !count &&
+		(sc.kernel_kind == RT_KERNEL_LOCKSTEP || (sc.kernel_kind == RT_KERNEL_AUTO && fp.max_bounces <= RT_LOCKSTEP_MAX_BOUNCES));
+	int tpw = fp.tiles_per_wave > 0 ? fp.tiles_per_wave : (lockstep ? (tiles * n_frames >= 16 * 8192 ? RT_LOCKSTEP_TILES : (tiles * n_frames >= 4 * 8192 ? 2 : 1))
+	                                                                 : pick_tiles_per_wave(accel, tiles * n_frames));
 	const long long waves = (tiles + tpw - 1) / tpw;
 #ifdef RT_EXPERIMENT
 	static const int env_block = [] { const char* e = getenv("RT355_BLOCK_THREADS"); int v = e ? atoi(e) : 0; return (v == 64 || v == 128 || v == 256) ? v : 0; }();
@@ -998,9 +1168,11 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 	} else if (sc.n_tris <= RT_LDS_MAX_TRIS) {
 		const size_t lds = (size_t)lds_stride_of(sc.n_tris) * sizeof(float);
 		if (count) hipLaunchKernelGGL((render_kernel<0, true>), grid, block, lds, stream, sc_sel, fp, tpw);
+		else if (lockstep) hipLaunchKernelGGL((render_lockstep_kernel<0>), grid, block, lds, stream, sc_sel, fp, tpw);
 		else hipLaunchKernelGGL((render_kernel<0, false>), grid, block, lds, stream, sc_sel, fp, tpw);
 	} else {
 		if (count) hipLaunchKernelGGL((render_kernel<1, true>), grid, block, 0, stream, sc_sel, fp, tpw);
+		else if (lockstep) hipLaunchKernelGGL((render_lockstep_kernel<1>), grid, block, 0, stream, sc_sel, fp, tpw);
 		else hipLaunchKernelGGL((render_kernel<1, false>), grid, block, 0, stream, sc_sel, fp, tpw);
 	}
 	hipError_t e = hipGetLastError();

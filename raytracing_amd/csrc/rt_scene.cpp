@@ -171,6 +171,7 @@ PlaneLayout flatten_planes(const std::vector<float>& tris, int stride, float pad
 		q = plane(PL_E0, i); q[0] = e0[0]; q[1] = e0[1]; q[2] = e0[2];
 		q = plane(PL_E1, i); q[0] = e1[0]; q[1] = e1[1]; q[2] = e1[2];
 		q = plane(PL_E2, i); q[0] = e2[0]; q[1] = e2[1]; q[2] = e2[2];
+		q = plane(PL_COL, i); q[0] = col[0]; q[1] = col[1]; q[2] = col[2]; q[3] = t[27];
 	}
 	// padded boxes of groups of RT_GROUP consecutive triangles
 	for (int g = 0; g < stride; g++) {      // every slot past the last group is an empty box

@@ -7,5 +7,5 @@ for w in spheres800 spheres4k; do
 for pk in 0 1; do
 for nh in 1 0; do
   if [ $nh = 1 ]; then export RT355_NO_HOIST=1; else unset RT355_NO_HOIST; fi
-  RT355_PACKET=$pk timeout -k 10 120 python bench.py --workload $w --steps 64 --warmup 32 --no-cpu | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$w packet=$pk nohoist=$nh', round(d['ms_per_step']*1000,1),'us', round(d['value']), d['unit'], 'frac', round(d['roofline']['frac'],4))"
+  RT355_PACKET=$pk timeout -k 10 120 python bench.py --workload $w --steps 4 --warmup 1 --no-cpu --no-configs | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$w packet=$pk nohoist=$nh', round(d['ms_per_frame']*1000,1),'us', round(d['value']), d['unit'], 'frac', round(d['roofline']['frac'],4))"
 done; done; done; done

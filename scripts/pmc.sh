@@ -3,7 +3,7 @@ tag=$1; shift
 out=gpurun_out/pmc_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $out -o a -- python3 bench.py --steps 8 --warmup 2 --no-cpu "$@" > $out/a.json 2> $out/a.err || exit 1
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $out -o a -- python3 bench.py --steps 4 --warmup 1 --no-cpu --no-configs "$@" > $out/a.json 2> $out/a.err || exit 1
 python3 - $out/a_counter_collection.csv <<'PY'
 import csv,sys,collections
 rows=list(csv.DictReader(open(sys.argv[1])))

@@ -2,8 +2,8 @@
 export TMPDIR=/tmp
 w=$1; shift
 o=gpurun_out/pmc_kcache_$w; rm -rf $o; mkdir -p $o
-timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_MISSES_DUPLICATE SQC_TC_DATA_READ_REQ SQC_TC_STALL --output-format csv -d $o/p1 -o p -- python3 bench.py --steps 32 --warmup 32 --no-cpu --workload $w "$@" > /dev/null 2> $o/p1.err || { echo "pass 1 failed"; tail -3 $o/p1.err; exit 1; }
-timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $o/p2 -o p -- python3 bench.py --steps 32 --warmup 32 --no-cpu --workload $w "$@" > /dev/null 2> $o/p2.err || { echo "pass 2 failed"; tail -3 $o/p2.err; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_MISSES_DUPLICATE SQC_TC_DATA_READ_REQ SQC_TC_STALL --output-format csv -d $o/p1 -o p -- python3 bench.py --steps 4 --warmup 1 --no-cpu --no-configs --workload $w "$@" > /dev/null 2> $o/p1.err || { echo "pass 1 failed"; tail -3 $o/p1.err; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $o/p2 -o p -- python3 bench.py --steps 4 --warmup 1 --no-cpu --no-configs --workload $w "$@" > /dev/null 2> $o/p2.err || { echo "pass 2 failed"; tail -3 $o/p2.err; exit 1; }
 python3 - $o <<'PY'
 import csv, sys, glob, os, collections
 o = sys.argv[1]

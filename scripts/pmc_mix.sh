@@ -2,8 +2,8 @@
 export TMPDIR=/tmp
 w=$1; pat=$2
 o=gpurun_out/pmc_mix_$w; rm -rf $o; mkdir -p $o
-timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT --output-format csv -d $o/p1 -o p -- python3 bench.py --steps 16 --warmup 16 --no-cpu --workload $w > /dev/null 2> $o/p1.err || { echo "pass 1 failed"; tail -3 $o/p1.err; exit 1; }
-timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_INT64 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH --output-format csv -d $o/p2 -o p -- python3 bench.py --steps 16 --warmup 16 --no-cpu --workload $w > /dev/null 2> $o/p2.err || { echo "pass 2 failed"; tail -3 $o/p2.err; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT --output-format csv -d $o/p1 -o p -- python3 bench.py --steps 4 --warmup 1 --no-cpu --no-configs --workload $w > /dev/null 2> $o/p1.err || { echo "pass 1 failed"; tail -3 $o/p1.err; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_INT64 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH --output-format csv -d $o/p2 -o p -- python3 bench.py --steps 4 --warmup 1 --no-cpu --no-configs --workload $w > /dev/null 2> $o/p2.err || { echo "pass 2 failed"; tail -3 $o/p2.err; exit 1; }
 python3 - $o "$pat" <<'PY'
 import csv, sys, glob, os, collections
 o, pat = sys.argv[1], sys.argv[2]

@@ -252,6 +252,45 @@ def test_tiles_per_wave_does_not_change_pixels():
             assert e.value.code == -1
 
 
+@pytest.mark.parametrize("name,size,depth", [("room", (200, 150), 1), ("room", (333, 77), 2), ("stock", (64, 64), 1),
+                                             ("mirrors", (192, 108), 16), ("mirrors", (96, 54), 0), ("two_lights", (80, 80), 1)])
+def test_both_kernel_forms_give_the_same_bits(oracle, name, size, depth):
+    """rt_scene_set_kernel: the lockstep form (all lanes of a tile in step; what AUTO picks up to depth 2)
+    and the state machine (lanes refilled as they finish; deep bounce loops) are the same arithmetic —
+    both are the oracle's frame at every depth, for whole frames, frame batches and row-tile shards."""
+    import torch
+    desc = scenes.get(name, w=size[0], h=size[1])
+    desc.depth = depth
+    want = oracle.render_desc(desc, threads=4)
+    tr = api.camera_trans(desc.cam_rot)
+    with api.Scene.from_desc(desc) as sc:
+        sc.commit(0, api.ACCEL_BRUTE)
+        for kind in (api.KERNEL_LOCKSTEP, api.KERNEL_STATE_MACHINE, api.KERNEL_AUTO):
+            sc.set_kernel(kind)
+            got = sc.render(desc.cam_pos, tr, desc.width, desc.height, desc.depth)
+            assert np.array_equal(_bits(got), _bits(want)), kind
+            for tpw in (1, 3):
+                sc.set_tiles_per_wave(tpw)
+                assert np.array_equal(_bits(sc.render(desc.cam_pos, tr, desc.width, desc.height, desc.depth)), _bits(want)), (kind, tpw)
+            sc.set_tiles_per_wave(0)
+            # a batch of 9 frames and an interleaved shard
+            n = desc.width * desc.height * 3
+            buf = torch.empty(9 * n, dtype=torch.float32, device="cuda:0")
+            sc.render_frames_device(0, np.tile(np.asarray(desc.cam_pos, np.float32), (9, 1)), np.tile(tr, (9, 1)), desc.width, desc.height,
+                                    desc.depth, api.STRICT, buf.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+            rows = api.shard_rows(desc.height, 5, 1, 3)
+            shard = torch.empty(rows * desc.width * 3, dtype=torch.float32, device="cuda:0")
+            sc.render_tiles_device(0, desc.cam_pos, tr, desc.width, desc.height, desc.depth, api.STRICT, 5, 1, 3, shard.data_ptr(),
+                                   torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(_bits(buf[8 * n:].cpu().numpy()), _bits(want.reshape(-1))), kind
+            sh = shard.cpu().numpy().reshape(rows, desc.width, 3)
+            picked = np.concatenate([want[r0:min(r0 + 5, desc.height)] for r0 in range(5, desc.height, 15)])
+            assert np.array_equal(_bits(sh), _bits(picked)), kind
+        with pytest.raises(api.RtError):
+            sc.set_kernel(3)
+
+
 def test_recommit_after_edit():
     desc = scenes.stock(64, 64)
     trans = api.camera_trans(desc.cam_rot)

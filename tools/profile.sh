@@ -7,12 +7,12 @@ tag=${1:-r01}
 out=gpurun_out/profiles_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-args="--steps 256 --warmup 32 --no-cpu"
+args="--steps 4 --warmup 1 --no-cpu --no-configs"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o room800 -- python3 bench.py $args > $out/bench_under_trace.json 2> $out/trace.err || exit 1
 cp $out/trace/room800_kernel_stats.csv $out/${tag}_room800_kernel_stats.csv
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE"; do
   name=$(echo $pass | cut -d' ' -f1)
-  timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d $out/pmc_$name -o p -- python3 bench.py --steps 64 --warmup 32 --no-cpu > /dev/null 2> $out/pmc_$name.err || exit 1
+  timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d $out/pmc_$name -o p -- python3 bench.py --steps 4 --warmup 1 --no-cpu --no-configs > /dev/null 2> $out/pmc_$name.err || exit 1
 done
 python3 - $out $tag <<'PY'
 import csv, sys, json, collections, glob, os
@@ -35,9 +35,9 @@ PY
 cat $out/${tag}_room800_kernel_stats.csv
 
 # ---- LBVH workload (config 4): kernel trace + SQ counters ----------------------------------------
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_lbvh -o spheres800 -- python3 bench.py --steps 64 --warmup 32 --no-cpu --workload spheres800 > $out/${tag}_spheres800_bench_under_rocprof.json 2> $out/trace_lbvh.err || exit 1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_lbvh -o spheres800 -- python3 bench.py --steps 4 --warmup 1 --no-cpu --no-configs --workload spheres800 > $out/${tag}_spheres800_bench_under_rocprof.json 2> $out/trace_lbvh.err || exit 1
 cp $out/trace_lbvh/spheres800_kernel_stats.csv $out/${tag}_spheres800_kernel_stats.csv
-timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $out/pmc_lbvh -o p -- python3 bench.py --steps 64 --warmup 32 --no-cpu --workload spheres800 > /dev/null 2> $out/pmc_lbvh.err || exit 1
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $out/pmc_lbvh -o p -- python3 bench.py --steps 4 --warmup 1 --no-cpu --no-configs --workload spheres800 > /dev/null 2> $out/pmc_lbvh.err || exit 1
 python3 - $out $tag <<'PY'
 import csv, sys, json, collections, os
 out, tag = sys.argv[1], sys.argv[2]
