@@ -258,8 +258,9 @@ int         rt_device_count(void);
  * most RT_TILES_PER_WAVE_MAX.  Pixels do not depend on it. */
 #define RT_TILES_PER_WAVE_MAX 1024
 int         rt_scene_set_tiles_per_wave(rt_scene* s, int tiles);
-/* Tuning knob of one scene: which form of the render kernel brute-force launches use.  Pixels do not
- * depend on it.  AUTO: lockstep up to max_bounces 2 (the reference's depth is 1), state machine beyond. */
+/* Tuning knob of one scene: which form of the render kernel brute-force and LBVH-packet launches use
+ * (the per-lane LBVH traversal always runs in the state machine).  Pixels do not depend on it.
+ * AUTO: lockstep up to max_bounces 2 (the reference's depth is 1), state machine beyond. */
 #define RT_KERNEL_AUTO          0
 #define RT_KERNEL_STATE_MACHINE 1   /* every lane its own stage, finished lanes refilled with new pixels: made for deep bounce loops */
 #define RT_KERNEL_LOCKSTEP      2   /* the 64 pixels of a tile stay in step: primary, mirror loop, one shadow ray per light */

@@ -130,10 +130,8 @@ void fill_frame(rt_scene* s, FrameParams& fp, const float cam[3], const float tr
 	fp.rcp_w = 1.0f / (float)w;
 	fp.rcp_h = 1.0f / (float)h;
 	fp.uv_fast = s->uv_fast ? 1 : 0;
-	memset(fp.cam, 0, sizeof fp.cam);
-	memset(fp.m, 0, sizeof fp.m);
-	memcpy(fp.cam[0], cam, 3 * sizeof(float));
-	memcpy(fp.m[0], trans16, 16 * sizeof(float));
+	memset(fp.pose, 0, sizeof fp.pose);
+	set_pose(fp, 0, cam, trans16);
 	fp.n_frames = 1;
 	fp.blocks_per_frame = 0;
 	fp.frame_stride = 0;
@@ -411,8 +409,7 @@ int rt_render_frames_device(rt_scene* s, int device, int n_frames, const float* 
 		FrameParams fp;
 		fill_frame(s, fp, cam_pos3 + 3 * (size_t)f0, trans16 + 16 * (size_t)f0, width, height, max_bounces);
 		for (int k = 0; k < nf; k++) {
-			memcpy(fp.cam[k], cam_pos3 + 3 * (size_t)(f0 + k), 3 * sizeof(float));
-			memcpy(fp.m[k], trans16 + 16 * (size_t)(f0 + k), 16 * sizeof(float));
+			set_pose(fp, k, cam_pos3 + 3 * (size_t)(f0 + k), trans16 + 16 * (size_t)(f0 + k));
 		}
 		fp.n_frames = nf;
 		fp.frame_stride = (long long)frame_stride_floats;

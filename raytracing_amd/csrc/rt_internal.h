@@ -88,10 +88,13 @@ struct DevScene {
 // One launch may render several frames of the same scene (a camera path: consecutive iterations
 // of the frame loop, Source.cpp:1126, with known poses): workgroups [f * blocks_per_frame,
 // (f+1) * blocks_per_frame) render frame f into out + f * frame_stride.
-#define RT_MAX_FRAMES 32      /* 2.4 KB of poses in the kernel arguments (4 KB limit) */
+#define RT_MAX_FRAMES 32      /* 1.5 KB of poses in the kernel arguments (4 KB limit) */
 struct FrameParams {
-	float cam[RT_MAX_FRAMES][3];    // camera.position            Source.cpp:545
-	float m[RT_MAX_FRAMES][16];     // trans, column-major        Source.cpp:1145-1147
+	// per frame: camera.position (Source.cpp:545), then what Source.cpp:537-545 needs of trans
+	// (Source.cpp:1145-1147, column-major): columns 0 and 1, and c = m2 * 0.5f + m3 * 1.0f, the part of
+	// (trans * vec4(u, v, 0.5, 1)).xyz that no pixel changes (set_pose computes it on the host with the
+	// same two roundings the reference makes per pixel)
+	float pose[RT_MAX_FRAMES][12];
 	int n_frames;
 	unsigned int blocks_per_frame;  // set by the launcher
 	// XCD-aware order of the workgroups of a multi-frame LBVH launch (0: off): the frame is cut into
@@ -192,6 +195,7 @@ PlaneLayout flatten_planes(const std::vector<float>& tris, int stride, float pad
 float scene_box(const std::vector<float>& tris, float lo[3], float hi[3]);   // returns the pad it applied
 
 // rt_kernels.hip
+void set_pose(FrameParams& fp, int k, const float cam[3], const float trans16[16]);
 DevScene dev_scene(const rt_scene* s, const DeviceState& d);
 bool use_packets(const DevScene& sc, const float trans16[16], int width, int height);   // the launcher's choice for an LBVH scene
 int launch_render(const DevScene& sc, const FrameParams& fp, int accel, int render_flags, bool count, hipStream_t stream);

@@ -455,16 +455,28 @@ __device__ __forceinline__ float exit_bound(const DevScene& sc, vec3 o, vec3 d) 
 	return te + fabsf(te) * 1e-4f;                       // NaN (all-NaN ray) is dropped by the caller's fminf
 }
 
-// x / 255.0 in binary64, correctly rounded, without the division sequence: Markstein's
-// q' = fma(r, c, q) with q = x*c, r = fma(-q, 255, x), c = RN(1/255) is the correctly rounded
-// quotient whenever q is finite (checked against exact rationals on 4e5 samples);
-// a non-finite q (x = +-inf or NaN) is already the quotient.
-__device__ __forceinline__ double div255(double x) {
-	const double c = 1.0 / 255.0;
-	const double q = x * c;
-	const double r = __builtin_fma(-q, 255.0, x);
-	const double q2 = __builtin_fma(r, c, q);
-	return (q - q == 0.0) ? q2 : q;
+// Source.cpp:488: `1.0f / (dist * dist) * l.intensity / 255.0 / 255.0f` — the two divisions are binary64
+// (255.0 is a double literal) and the result is rounded to binary32 when it is stored in `modify`.
+// For every binary32 x that is the same value as ONE binary32 division x / 65025.0f: the exact
+// quotient x / 65025 is never closer to a binary32 rounding boundary than 2^-42 relative (65025 * odd
+// 25-bit midpoint needs 39+ significant bits, x has 24), while the two binary64 roundings move it by
+// 2^-52 at most, so both round to the same binary32.  Checked exhaustively, bit for bit, over all 2^31
+// non-negative binary32 values and +inf against the binary64 form.
+#ifndef RT_DIV65025_FAST
+#define RT_DIV65025_FAST 0
+#endif
+__device__ __forceinline__ float div65025(float x) {
+#if RT_DIV65025_FAST
+	// division by the constant without the division sequence (Markstein): exhaustively equal to x / 65025.0f
+	// for every finite binary32 x with |x| in [2^-100, 2^100] (scripts/ubench/div65025.hip), the IEEE sequence outside
+	const float c = 1.0f / 65025.0f;
+	const float q = x * c;
+	const float q2 = __builtin_fmaf(__builtin_fmaf(-q, 65025.0f, x), c, q);
+	const float ax = fabsf(x);
+	return (ax >= 0x1p-100f && ax <= 0x1p100f) ? q2 : x / 65025.0f;
+#else
+	return x / 65025.0f;
+#endif
 }
 
 // ---- pixel <-> work index ------------------------------------------------------------------
@@ -522,11 +534,11 @@ __device__ __forceinline__ vec3 primary_dir(int x, int y, const FrameParams& fp,
 		v = (float)(((double)y - (double)hh / 2.0) / (double)(float)hh);
 		u = (float)(((double)x - (double)ww / 2.0) / (double)(float)ww);
 	}
-	const float* m = fp.m[frame];
+	const float* m = fp.pose[frame];       // 3..5: column 0, 6..8: column 1, 9..11: m2 * 0.5f + m3 * 1.0f (set_pose)
 	vec3 r;
-	r.x = (m[0] * u + m[4] * v) + (m[8] * 0.5f + m[12] * 1.0f);
-	r.y = (m[1] * u + m[5] * v) + (m[9] * 0.5f + m[13] * 1.0f);
-	r.z = (m[2] * u + m[6] * v) + (m[10] * 0.5f + m[14] * 1.0f);
+	r.x = (m[3] * u + m[6] * v) + m[9];
+	r.y = (m[4] * u + m[7] * v) + m[10];
+	r.z = (m[5] * u + m[8] * v) + m[11];
 	return r;
 }
 
@@ -648,15 +660,16 @@ __device__ __forceinline__ Hit trace_brute(const DevScene& sc, const float* lds_
 	const float ex = fminf(fminf(fmaxf(__builtin_fmaf(sc.bb_lo[0], inv.x, oi.x), __builtin_fmaf(sc.bb_hi[0], inv.x, oi.x)),
 	                             fmaxf(__builtin_fmaf(sc.bb_lo[1], inv.y, oi.y), __builtin_fmaf(sc.bb_hi[1], inv.y, oi.y))),
 	                       fmaxf(__builtin_fmaf(sc.bb_lo[2], inv.z, oi.z), __builtin_fmaf(sc.bb_hi[2], inv.z, oi.z)));
-	float lim = near ? fminf(ex + fabsf(ex) * 1e-4f, 1e9f) : 1e9f;       // 1e9: Source.cpp:278
+	float lim = fminf(ex + fabsf(ex) * 1e-4f, 1e9f);                     // 1e9: Source.cpp:278
+	const bool some_far = __builtin_amdgcn_ballot_w64(live && !near) != 0ull;      // (rays from beyond far_guard: rare, wave-uniform branch)
+	if (some_far && !near) { lim = 1e9f; inv = make3(0.f, 0.f, 0.f); oi = make3(0.f, 0.f, 0.f); }
 	if constexpr (KIND == RAY_SHADOW) lim = fminf(lim, __uint_as_float(__float_as_uint(dist) + 1u));   // first float > dist (Source.cpp:476)
 	lim = fminf(lim, 1e9f);
 	if (!live) lim = -1.0f;
-	if (!near) { inv = make3(0.f, 0.f, 0.f); oi = make3(0.f, 0.f, 0.f); }
 	const unsigned int lane_oct = (__float_as_uint(ds.x) >> 31) | ((__float_as_uint(ds.y) >> 31) << 1) | ((__float_as_uint(ds.z) >> 31) << 2);
 	const unsigned long long lv = __builtin_amdgcn_ballot_w64(live);
 	const int oct = (int)__builtin_amdgcn_readlane(lane_oct, lv ? __builtin_ctzll(lv) : 0);
-	const bool oct_uniform = __builtin_amdgcn_ballot_w64(live && (lane_oct != (unsigned int)oct || !near)) == 0ull;
+	const bool oct_uniform = !some_far && __builtin_amdgcn_ballot_w64(live && lane_oct != (unsigned int)oct) == 0ull;
 	c4ptr tri;
 	tri.p = (const __attribute__((address_space(4))) v4f*)(unsigned long long)sc.planes;
 	constexpr bool first_only = KIND == RAY_SHADOW;
@@ -665,6 +678,46 @@ __device__ __forceinline__ Hit trace_brute(const DevScene& sc, const float* lds_
 		else return cast_ray_pruned<false, true>(sc, tri, oct, lds_num0, o, d, inv, oi, skip, lim, first_only, wp);
 	}
 	return cast_ray_pruned<false, false>(sc, tri, 0, lds_num0, o, d, inv, oi, skip, lim, first_only, wp);
+}
+
+// castRay over the LBVH by packets for ONE kind of ray (lockstep kernel): one walk per direction octant
+// present among the live lanes (one pass for almost every wave).  Same set-up as trace<3>.
+template <int KIND>
+__device__ __forceinline__ Hit trace_packet(const DevScene& sc, vec3 o, vec3 d, int skip, bool live, float dist, WaveProf& wp) {
+	const vec3 ds = make3(fabsf(d.x) < 1e-30f ? 1e-30f : d.x, fabsf(d.y) < 1e-30f ? 1e-30f : d.y, fabsf(d.z) < 1e-30f ? 1e-30f : d.z);
+	const bool near = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) < sc.far_guard;   // false for NaN too
+	vec3 inv = make3(__builtin_amdgcn_rcpf(ds.x), __builtin_amdgcn_rcpf(ds.y), __builtin_amdgcn_rcpf(ds.z));
+	vec3 oi = make3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
+	const float ex = fminf(fminf(fmaxf(__builtin_fmaf(sc.bb_lo[0], inv.x, oi.x), __builtin_fmaf(sc.bb_hi[0], inv.x, oi.x)),
+	                             fmaxf(__builtin_fmaf(sc.bb_lo[1], inv.y, oi.y), __builtin_fmaf(sc.bb_hi[1], inv.y, oi.y))),
+	                       fmaxf(__builtin_fmaf(sc.bb_lo[2], inv.z, oi.z), __builtin_fmaf(sc.bb_hi[2], inv.z, oi.z)));
+	float lim = fminf(ex + fabsf(ex) * 1e-4f, 1e9f);
+	if (__builtin_amdgcn_ballot_w64(live && !near) != 0ull) {          // rays from beyond far_guard: every box tests as hit for them
+		if (!near) { lim = 1e9f; inv = make3(0.f, 0.f, 0.f); oi = make3(0.f, 0.f, 0.f); }
+	}
+	if constexpr (KIND == RAY_SHADOW) lim = fminf(lim, __uint_as_float(__float_as_uint(dist) + 1u));
+	lim = fminf(lim, 1e9f);
+	const unsigned int lane_oct = (__float_as_uint(ds.x) >> 31) | ((__float_as_uint(ds.y) >> 31) << 1) | ((__float_as_uint(ds.z) >> 31) << 2);
+	unsigned long long todo = __builtin_amdgcn_ballot_w64(live);
+	Hit h;
+	h.t = 1e9f;
+	h.idx = -1;
+	h.p = make3(0.f, 0.f, 0.f);
+	LaneCounters lc = { 0, 0, 0, 0 };
+	while (todo) {
+		const unsigned int oct = __builtin_amdgcn_readlane(lane_oct, __builtin_ctzll(todo));
+		const bool mine = live && lane_oct == oct;
+		todo &= ~__builtin_amdgcn_ballot_w64(mine);
+		const Hit hp = cast_ray_packet<false>(sc, (int)oct, o, d, inv, oi, skip, mine ? lim : -1.0f, KIND == RAY_SHADOW, lc, wp);
+		if (mine) h = hp;
+	}
+	return h;
+}
+
+template <int ACCEL, int KIND>
+__device__ __forceinline__ Hit trace_kind(const DevScene& sc, const float* lds_num0, vec3 o, vec3 d, int skip, bool live, float dist, WaveProf& wp) {
+	if constexpr (ACCEL == 3) return trace_packet<KIND>(sc, o, d, skip, live, dist, wp);
+	else return trace_brute<ACCEL, KIND>(sc, lds_num0, o, d, skip, live, dist, wp);
 }
 
 // Per-lane attribute fetch by hit index (shininess Source.cpp:570/575, normal :561, colour :489).
@@ -701,7 +754,7 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 			if (block_in_frame >= fp.blocks_per_frame) return;       // (the last band is padded; no barrier in these kernels)
 		}
 	}
-	const vec3 cam = make3(fp.cam[frame][0], fp.cam[frame][1], fp.cam[frame][2]);
+	const vec3 cam = make3(fp.pose[frame][0], fp.pose[frame][1], fp.pose[frame][2]);
 	if constexpr (ACCEL == 0) {
 		// numerator of Source.cpp:383 for rays that start at the camera: the one per-workgroup table
 		// (the scene itself is read through the scalar cache, see cast_ray_pruned)
@@ -832,7 +885,7 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 		} else if (stage == ST_SHADOW) {
 			if (!hit || h.t > dist) {                                        // Source.cpp:476
 				const float f = 1.0f / (dist * dist) * intensity;            // Source.cpp:488
-				const float modify = (float)div255(div255((double)f));       // ... / 255.0 / 255.0f, in double
+				const float modify = div65025(f);                            // ... / 255.0 / 255.0f: binary64 divisions, rounded to binary32
 				const float cr = tri_plane<ACCEL>(sc, s_tri, lds_stride, PL_P1, hidx).w;
 				const float cg = tri_plane<ACCEL>(sc, s_tri, lds_stride, PL_P2, hidx).w;
 				const float cb = tri_plane<ACCEL>(sc, s_tri, lds_stride, PL_P3, hidx).w;
@@ -920,12 +973,21 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 #define RT_LOCKSTEP_MAX_BOUNCES 2     /* deeper bounce loops go to the state machine, which refills idle lanes */
 #endif
 template <int ACCEL>
-__global__ void __launch_bounds__(256, RT_MIN_WAVES) render_lockstep_kernel(DevScene sc, FrameParams fp, int tiles_per_wave) {
+__global__ void __launch_bounds__(256, ACCEL == 3 ? RT_MIN_WAVES_PACKET : RT_MIN_WAVES) render_lockstep_kernel(DevScene sc, FrameParams fp, int tiles_per_wave) {
 	extern __shared__ float4 s_tri[];
 	float* s_num0 = (float*)s_tri;
-	const int frame = fp.n_frames > 1 ? (int)(blockIdx.x / fp.blocks_per_frame) : 0;      // workgroup-uniform
-	const unsigned int block_in_frame = blockIdx.x - (unsigned int)frame * fp.blocks_per_frame;
-	const vec3 cam = make3(fp.cam[frame][0], fp.cam[frame][1], fp.cam[frame][2]);
+	int frame = fp.n_frames > 1 ? (int)(blockIdx.x / fp.blocks_per_frame) : 0;      // workgroup-uniform
+	unsigned int block_in_frame = blockIdx.x - (unsigned int)frame * fp.blocks_per_frame;
+	if constexpr (ACCEL == 3) {
+		if (fp.band_blocks > 0) {          // XCD-aware order (rt_internal.h FrameParams::band_blocks), as in render_kernel
+			const unsigned int xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+			frame = (int)(j / fp.band_blocks);
+			const unsigned int band = (xcd + (unsigned int)frame) & 7u;
+			block_in_frame = band * fp.band_blocks + (j - (unsigned int)frame * fp.band_blocks);
+			if (block_in_frame >= fp.blocks_per_frame) return;       // (the last band is padded; no barrier in this instance)
+		}
+	}
+	const vec3 cam = make3(fp.pose[frame][0], fp.pose[frame][1], fp.pose[frame][2]);
 	if constexpr (ACCEL == 0) {
 		// numerator of Source.cpp:383 for rays that start at the camera (see render_kernel)
 		const int lds_stride = lds_stride_of(sc.n_tris);
@@ -952,7 +1014,7 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES) render_lockstep_kernel(DevS
 		if (++tx == tiles_x) { tx = 0; ty++; }
 		// ---- primary ray (Source.cpp:534-548)
 		const vec3 d = primary_dir(x, global_row(ly, fp), fp, frame);
-		const Hit h = trace_brute<ACCEL, RAY_PRIMARY>(sc, s_num0, cam, d, -1, inside, 0.f, wp);
+		const Hit h = trace_kind<ACCEL, RAY_PRIMARY>(sc, s_num0, cam, d, -1, inside, 0.f, wp);
 		const bool hit = inside && h.idx >= 0;
 		float4 A = make_float4(0.f, 0.f, 0.f, 0.f);                          // colour, shininess of the triangle to be lit
 		if (hit) A = sc.planes[PL_COL * sc.stride + h.idx];
@@ -971,7 +1033,7 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES) render_lockstep_kernel(DevS
 				bd = normalize(reflect(d, face_normal(d, xyz(N4))));         // Source.cpp:561, 572
 			}
 			while (__builtin_amdgcn_ballot_w64(bouncing) != 0ull) {
-				const Hit g = trace_brute<ACCEL, RAY_BOUNCE>(sc, s_num0, bo, bd, bskip, bouncing, 0.f, wp);   // Source.cpp:573, 578
+				const Hit g = trace_kind<ACCEL, RAY_BOUNCE>(sc, s_num0, bo, bd, bskip, bouncing, 0.f, wp);   // Source.cpp:573, 578
 				const bool ghit = bouncing && g.idx >= 0;
 				float4 GA = make_float4(0.f, 0.f, 0.f, 0.f);
 				if (ghit) GA = sc.planes[PL_COL * sc.stride + g.idx];
@@ -1003,10 +1065,10 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES) render_lockstep_kernel(DevS
 				const float s = sqrtf(dot(ray, ray));                        // magnitude(ray), Source.cpp:26-28
 				const float inv = 1.0f / s;                                  // glm::normalize: v * inversesqrt(dot(v,v))
 				const vec3 ld = ray * inv;
-				const Hit sh = trace_brute<ACCEL, RAY_SHADOW>(sc, s_num0, hp, ld, hidx, shade, s, wp);   // Source.cpp:473
+				const Hit sh = trace_kind<ACCEL, RAY_SHADOW>(sc, s_num0, hp, ld, hidx, shade, s, wp);   // Source.cpp:473
 				if (shade && (!(sh.idx >= 0) || sh.t > s)) {                 // Source.cpp:476
 					const float f = 1.0f / (s * s) * L.w;                    // Source.cpp:488
-					const float modify = (float)div255(div255((double)f));   // ... / 255.0 / 255.0f, in double
+					const float modify = div65025(f);                        // ... / 255.0 / 255.0f: binary64 divisions, rounded to binary32
 					color.x = color.x + modify * A.x;                        // Source.cpp:489
 					color.y = color.y + modify * A.y;
 					color.z = color.z + modify * A.z;
@@ -1055,6 +1117,16 @@ __global__ void __launch_bounds__(256) cast_rays_kernel(DevScene sc, int n, cons
 
 // ---- host launchers ----------------------------------------------------------------------------
 
+void set_pose(FrameParams& fp, int k, const float cam[3], const float trans16[16]) {
+	float* p = fp.pose[k];
+	for (int a = 0; a < 3; a++) {
+		p[a] = cam[a];
+		p[3 + a] = trans16[a];
+		p[6 + a] = trans16[4 + a];
+		p[9 + a] = trans16[8 + a] * 0.5f + trans16[12 + a] * 1.0f;       // Source.cpp:537-545: (m2 * 0.5 + m3 * 1), unfused
+	}
+}
+
 DevScene dev_scene(const rt_scene* s, const DeviceState& d) {
 	DevScene sc;
 	sc.planes = (const float4*)d.planes;
@@ -1082,7 +1154,11 @@ DevScene dev_scene(const rt_scene* s, const DeviceState& d) {
 	return sc;
 }
 
+static bool use_packets_cols(const DevScene& sc, const float col0[3], const float col1[3], int width, int height);
 bool use_packets(const DevScene& sc, const float trans16[16], int width, int height) {
+	return use_packets_cols(sc, trans16, trans16 + 4, width, height);
+}
+static bool use_packets_cols(const DevScene& sc, const float col0[3], const float col1[3], int width, int height) {
 	if (sc.skip_count <= 0) return false;
 	if (!sc.per_lane_ok) return true;        // the 4-wide tree is too deep for the per-lane stack (rt_lbvh.hip tree_depths)
 	if (sc.traversal != RT_TRAVERSAL_AUTO) return sc.traversal == RT_TRAVERSAL_PACKET;
@@ -1090,9 +1166,8 @@ bool use_packets(const DevScene& sc, const float trans16[16], int width, int hei
 	static const int env_packet = [] { const char* e = getenv("RT355_PACKET"); return e ? atoi(e) : -1; }();
 	if (env_packet >= 0) return env_packet != 0;
 #endif
-	const float* m = trans16;
-	const float du = sqrtf(m[0] * m[0] + m[1] * m[1] + m[2] * m[2]) / (float)(width > 0 ? width : 1);
-	const float dv = sqrtf(m[4] * m[4] + m[5] * m[5] + m[6] * m[6]) / (float)(height > 0 ? height : 1);
+	const float du = sqrtf(col0[0] * col0[0] + col0[1] * col0[1] + col0[2] * col0[2]) / (float)(width > 0 ? width : 1);
+	const float dv = sqrtf(col1[0] * col1[0] + col1[1] * col1[1] + col1[2] * col1[2]) / (float)(height > 0 ? height : 1);
 	const float footprint = 8.0f * 0.5f * (du + dv) * sc.packet_scale;
 	return footprint < 5.0f;
 }
@@ -1117,10 +1192,10 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 	if (tiles * 64 > 0xf0000000LL) { set_error("rt_render: %dx%d needs more than 2^32 work items", fp.width, fp.local_rows); return RT_ERR_LIMIT; }
 	// brute force at the reference's bounce depth: the lockstep kernel (its tiles are walked one after the
 	// other, so longer runs only amortise the per-workgroup set-up; measured best at 4)
-	const bool lockstep = accel != RT_ACCEL_LBVH && !count &&
-		(sc.kernel_kind == RT_KERNEL_LOCKSTEP || (sc.kernel_kind == RT_KERNEL_AUTO && fp.max_bounces <= RT_LOCKSTEP_MAX_BOUNCES));
-	int tpw = fp.tiles_per_wave > 0 ? fp.tiles_per_wave : (lockstep ? (tiles * n_frames >= 16 * 8192 ? RT_LOCKSTEP_TILES : (tiles * n_frames >= 4 * 8192 ? 2 : 1))
-	                                                                 : pick_tiles_per_wave(accel, tiles * n_frames));
+	// (LBVH: the packet traversal has a lockstep form too; the per-lane traversal stays with the state machine)
+	const bool lockstep = !count && (sc.kernel_kind == RT_KERNEL_LOCKSTEP || (sc.kernel_kind == RT_KERNEL_AUTO && fp.max_bounces <= RT_LOCKSTEP_MAX_BOUNCES));
+	int tpw = fp.tiles_per_wave > 0 ? fp.tiles_per_wave : (lockstep && accel != RT_ACCEL_LBVH ? (tiles * n_frames >= 16 * 8192 ? RT_LOCKSTEP_TILES : (tiles * n_frames >= 4 * 8192 ? 2 : 1))
+	                                                                                           : pick_tiles_per_wave(accel, tiles * n_frames));
 	const long long waves = (tiles + tpw - 1) / tpw;
 #ifdef RT_EXPERIMENT
 	static const int env_block = [] { const char* e = getenv("RT355_BLOCK_THREADS"); int v = e ? atoi(e) : 0; return (v == 64 || v == 128 || v == 256) ? v : 0; }();
@@ -1138,7 +1213,7 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 	// of the mean triangle size; measured on the 100k-triangle scene: packets win below ~5 (800x800: 4.6, +3 %; 1200: 3.1,
 	// 1.27x; 1600: 2.3, 1.4x; 2400: 1.5, 1.6x; 3840x2160: 1.3, 1.7x) and lose above (400x400: 9.2, 0.6x).
 	DevScene sc_sel = sc;
-	if (accel == RT_ACCEL_LBVH && !use_packets(sc, fp.m[0], fp.width, fp.height)) sc_sel.skip_count = 0;
+	if (accel == RT_ACCEL_LBVH && !use_packets_cols(sc, fp.pose[0] + 3, fp.pose[0] + 6, fp.width, fp.height)) sc_sel.skip_count = 0;
 	dim3 grid((unsigned)(blocks * n_frames)), block((unsigned)threads);
 	// XCD-aware workgroup order for multi-frame LBVH launches (rt_internal.h FrameParams::band_blocks).
 	// Measured on the 100k-triangle scene, 32 frames per launch, us/frame without | with: 800x800 76 | 72
@@ -1163,6 +1238,7 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 		const size_t lds = (size_t)RT_STACK_LDS * RT_STACK_PITCH * sizeof(int);   // [entry][lane]
 		if (count && sc_sel.skip_count > 0) hipLaunchKernelGGL((render_kernel<3, true>), grid, block, 0, stream, sc_sel, fp, tpw);   // the traversal the frame really gets
 		else if (count) hipLaunchKernelGGL((render_kernel<2, true>), grid, block, lds, stream, sc_sel, fp, tpw);
+		else if (sc_sel.skip_count > 0 && lockstep) hipLaunchKernelGGL((render_lockstep_kernel<3>), grid, block, 0, stream, sc_sel, fp, tpw);
 		else if (sc_sel.skip_count > 0) hipLaunchKernelGGL((render_kernel<3, false>), grid, block, 0, stream, sc_sel, fp, tpw);
 		else hipLaunchKernelGGL((render_kernel<2, false>), grid, block, lds, stream, sc_sel, fp, tpw);
 	} else if (sc.n_tris <= RT_LDS_MAX_TRIS) {

@@ -116,8 +116,10 @@ def test_frame_batches_through_the_tree_equal_single_frames():
         n = w * h * 3
         with api.Scene.from_desc(desc) as sc:
             sc.commit(0, api.ACCEL_LBVH)
-            for mode in (api.TRAVERSAL_PER_LANE, api.TRAVERSAL_PACKET):
+            for mode, kind in ((api.TRAVERSAL_PER_LANE, api.KERNEL_AUTO), (api.TRAVERSAL_PACKET, api.KERNEL_LOCKSTEP),
+                               (api.TRAVERSAL_PACKET, api.KERNEL_STATE_MACHINE)):
                 sc.set_traversal(mode)
+                sc.set_kernel(kind)
                 singles = [sc.render(cams[i], trs[i], w, h, desc.depth) for i in range(19)]
                 buf = torch.full((19 * n,), -1.0, dtype=torch.float32, device="cuda:0")
                 sc.render_frames_device(0, cams, trs, w, h, desc.depth, api.STRICT, buf.data_ptr(), n,
@@ -125,7 +127,7 @@ def test_frame_batches_through_the_tree_equal_single_frames():
                 torch.cuda.synchronize()
                 got = buf.cpu().numpy().reshape(19, h, w, 3)
                 for i in range(19):
-                    assert np.array_equal(_bits(got[i]), _bits(singles[i])), (w, h, mode, i)
+                    assert np.array_equal(_bits(got[i]), _bits(singles[i])), (w, h, mode, kind, i)
         assert not np.array_equal(singles[0], singles[18])
 
 

@@ -22,7 +22,12 @@ def _lbvh_frame(desc):
         sc.set_traversal(api.TRAVERSAL_PACKET)
         sc.commit(0, api.ACCEL_LBVH)
         assert sc.traversal(0, api.camera_trans(desc.cam_rot), desc.width, desc.height) == api.TRAVERSAL_PACKET
-        return sc.render(desc.cam_pos, api.camera_trans(desc.cam_rot), desc.width, desc.height, desc.depth)
+        frames = []
+        for kind in (api.KERNEL_AUTO, api.KERNEL_LOCKSTEP, api.KERNEL_STATE_MACHINE):     # both forms of the render kernel walk by packets
+            sc.set_kernel(kind)
+            frames.append(sc.render(desc.cam_pos, api.camera_trans(desc.cam_rot), desc.width, desc.height, desc.depth))
+        assert np.array_equal(_bits(frames[0]), _bits(frames[1])) and np.array_equal(_bits(frames[0]), _bits(frames[2]))
+        return frames[0]
 
 
 @pytest.mark.parametrize("case", [c for c in golden_cases() if c not in ("empty_16x8",)])
