@@ -310,6 +310,10 @@ int rt_scene_commit(rt_scene* s, int device, int accel_flags) {
 		d.packet_scale = (mean > 0.0 && box_finite) ? (float)(sqrt(diag) / mean) : 3.0e38f;
 	}
 	if (d.accel == RT_ACCEL_LBVH) {
+		// the tree's leaf boxes carry a tenth of the pad plus 1e-3 of the triangle's own size (rt_lbvh.hip
+		// tri_box_padded): the slab arithmetic stays inside that for origins up to 30 scene scales away
+		const float g = pad * 3e4f;
+		if (d.far_guard > g) d.far_guard = g;
 		int rc = lbvh_build(s, d, nullptr);
 		if (rc != RT_OK) return rc;
 	}

@@ -322,6 +322,13 @@ __device__ __forceinline__ void packet_leaf(c4ptr T, int i, vec3 o, vec3 d, int 
 	}
 }
 
+// v_writelane with a wave-uniform value and lane index (both SGPRs: the lane index goes through m0)
+__device__ __forceinline__ void wave_set_lane(int& v, int value, int lane) {
+	int m0_saved;
+	asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+	             : "+v"(v), "=&s"(m0_saved) : "s"(value), "s"(lane));
+}
+
 template <bool COUNT>
 __device__ __forceinline__ Hit cast_ray_packet(const DevScene& sc, int oct, vec3 o, vec3 d, vec3 inv, vec3 oi,
                                                int skip, float lim, bool first_only, LaneCounters& lc, WaveProf& wp) {
@@ -374,13 +381,7 @@ __device__ __forceinline__ Hit cast_ray_packet(const DevScene& sc, int oct, vec3
 		const bool hitB = __builtin_amdgcn_ballot_w64(slab_hit_oct(q2, q3, inv, oi, lim_hi)) != 0;
 		if (hitB) {
 			if (refB < 0) packet_leaf<COUNT>(aos.offset_floats((long long)(~refB) * 32), ~refB, o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp);
-			else if (next >= 0) {
-				// v_writelane with a scalar value takes its lane index from m0 (one constant-bus operand); m0 is put back
-				int m0_saved;
-				asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
-				             : "+v"(stackv), "=&s"(m0_saved) : "s"(refB), "s"(sp));
-				sp++;
-			}
+			else if (next >= 0) wave_set_lane(stackv, refB, sp++);
 			else next = refB;
 		}
 		if (next < 0) {

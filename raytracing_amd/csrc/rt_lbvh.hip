@@ -62,6 +62,25 @@ __device__ __forceinline__ void tri_box(const float4* __restrict__ planes, int s
 
 struct BoxF { float lo[3], hi[3]; };
 
+// Padded box of ONE triangle as the tree's leaves, the hoisted list and the per-lane leaf resolution use
+// it.  Boxes only ever skip work; what the pad has to cover is (1) the rounding of the slab arithmetic,
+// about 5e-7 of the scene scale S for origins inside the scene and 30 times that at the far_guard of an
+// LBVH commit (30 S, rt_api.cpp), and (2) hit points the reference's own edge tests accept beyond a
+// needle's tips, about 1e-7 * aspect ratio * its length L.  pad = 1e-4 S + 1e-3 L covers (1) six times over
+// and (2) up to an aspect of 1:10^4, as the flat 1e-3 S of round 1 did for scene-sized needles — and for
+// the 0.05-unit triangles of the 100k-triangle scene it is 0.002 instead of 0.02: boxes of 0.054 instead
+// of 0.09 a side, about a third of the box hits at the leaves.
+#ifndef RT_LEAF_PAD_SCENE
+#define RT_LEAF_PAD_SCENE 0.1f     /* of the commit's pad (1e-3 S) */
+#endif
+__device__ __forceinline__ void tri_box_padded(const float4* __restrict__ planes, int stride, int i, float pad, float lo[3], float hi[3]) {
+	tri_box(planes, stride, i, lo, hi);
+	const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+	const float p = pad * RT_LEAF_PAD_SCENE + 1e-3f * sqrtf(dx * dx + dy * dy + dz * dz);
+#pragma unroll
+	for (int k = 0; k < 3; k++) { lo[k] -= p; hi[k] += p; }
+}
+
 // key = (Morton code, as many leading bits as fit) : (triangle index in `index_bits` bits); 63 bits in all
 __global__ void __launch_bounds__(256) k_morton(const float4* __restrict__ planes, int stride, int n, BoxF scene, int index_bits,
                                                u64* __restrict__ keys) {
@@ -137,9 +156,7 @@ __global__ void __launch_bounds__(256) k_refit(const float4* __restrict__ planes
 	if (p >= n) return;
 	const int tri = (int)((unsigned int)keys[p] & index_mask);
 	float lo[3], hi[3];
-	tri_box(planes, stride, tri, lo, hi);
-#pragma unroll
-	for (int k = 0; k < 3; k++) { lo[k] -= pad; hi[k] += pad; }
+	tri_box_padded(planes, stride, tri, pad, lo, hi);
 	int link = parent_leaf[p];
 	// every lane's walk ends: at a node it reaches first, or at the root
 	for (int guard = 0; guard < 128 && link >= 0; guard++) {
@@ -336,8 +353,7 @@ __global__ void __launch_bounds__(64) k_hoist(const float4* __restrict__ planes,
 	o[6] = planes[PL_E2 * stride + i];
 	o[7] = make_float4(0.f, 0.f, 0.f, 0.f);
 	float lo[3], hi[3];
-	tri_box(planes, stride, i, lo, hi);
-	for (int a = 0; a < 3; a++) { lo[a] -= pad; hi[a] += pad; }
+	tri_box_padded(planes, stride, i, pad, lo, hi);
 	for (int oct = 0; oct < 8; oct++) {
 		float nr[3], fr[3];
 		for (int a = 0; a < 3; a++) {
