@@ -351,13 +351,17 @@ __device__ __forceinline__ Hit cast_ray_packet(const DevScene& sc, int oct, vec3
 		c4ptr hrec;
 		hrec.p = (const __attribute__((address_space(4))) v4f*)(unsigned long long)sc.hoist;
 		const c4ptr hbox = hrec.offset_floats((long long)sc.hoist_count * 32 + (long long)oct * sc.hoist_count * 8);
-		for (int j = 0; j < sc.hoist_count; j++) {
+		for (int j = 0; j < sc.hoist_count;) {
 			const c4ptr R = hbox.offset_floats((long long)j * 8);
 			const float4 a0 = R[0], a1 = R[1];
+			const int second = __float_as_int(a1.z);         // a partner with the same box follows (rt_lbvh.hip k_hoist), or -1
 			RT_PROF(wp, WP_INBOX);
 			if constexpr (COUNT) lc.box += lim >= 0.0f;
-			if (__builtin_amdgcn_ballot_w64(slab_hit_oct(a0, a1, inv, oi, lim_hi)) != 0)
+			if (__builtin_amdgcn_ballot_w64(slab_hit_oct(a0, a1, inv, oi, lim_hi)) != 0) {
 				packet_leaf<COUNT>(hrec.offset_floats((long long)j * 32), __float_as_int(a1.w), o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp);
+				if (second >= 0) packet_leaf<COUNT>(hrec.offset_floats((long long)(j + 1) * 32), second, o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp);
+			}
+			j += second >= 0 ? 2 : 1;
 		}
 		if (__builtin_amdgcn_ballot_w64(lim >= 0.0f) == 0) return h;            // (shadow rays that all have their hit)
 	}
@@ -413,33 +417,41 @@ __device__ __forceinline__ void hoisted_tests(const DevScene& sc, vec3 o, vec3 d
 	c4ptr T;
 	T.p = (const __attribute__((address_space(4))) v4f*)(unsigned long long)sc.hoist;
 	c4ptr B = T.offset_floats((long long)sc.hoist_count * 32);                           // octant 0: near = lo, far = hi
-	for (int j = 0; j < sc.hoist_count; j++, T = T.offset_floats(32), B = B.offset_floats(8)) {
+	for (int j = 0; j < sc.hoist_count;) {
 		const float4 b0 = B[0], b1 = B[1];
+		const int second = __float_as_int(b1.z);             // a partner with the same box follows (rt_lbvh.hip k_hoist), or -1
+		const int members = second >= 0 ? 2 : 1;
 		if constexpr (COUNT) lc.box += live;
-		if (__builtin_amdgcn_ballot_w64(live && slab_hit(b0, make_float4(b0.w, b1.x, b1.y, 0.f), inv, oi, lim_hi)) == 0) continue;
-		RT_PROF(wp, WP_TRI);
-		const int i = __float_as_int(b1.w);
-		const float4 N4 = T[0], P14 = T[1];
-		const vec3 nn = xyz(N4), p1 = xyz(P14);
-		const float t = dot(p1 - o, nn) / dot(d, nn);                           // Source.cpp:383
-		const bool visit = live && i != skip;                                   // Source.cpp:302
-		const bool cand = visit && (t > RT_EPS_BELOW) && (t < lim);             // Source.cpp:385, 391
-		if constexpr (COUNT) { lc.plane += visit; lc.point += visit && !(t < 0.0f); lc.edge += cand; }
-		if (__builtin_amdgcn_ballot_w64(cand) == 0) continue;
-		const float4 P24 = T[2], P34 = T[3], E0 = T[4], E1 = T[5], E2 = T[6];
-		const vec3 I = make3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);      // Source.cpp:389
-		const bool c0 = cand && (dot(nn, cross(xyz(E0), I - p1)) > 0.0f);       // Source.cpp:392
-		if constexpr (COUNT) lc.edge += c0;
-		if (__builtin_amdgcn_ballot_w64(c0) == 0) continue;
-		const bool c1 = c0 && (dot(nn, cross(xyz(E1), I - xyz(P24))) > 0.0f);   // Source.cpp:393
-		if constexpr (COUNT) lc.edge += c1;
-		if (__builtin_amdgcn_ballot_w64(c1) == 0) continue;
-		const bool c2 = c1 && (dot(nn, cross(xyz(E2), I - xyz(P34))) > 0.0f);   // Source.cpp:394
-		if (c2) {                                                               // Source.cpp:396
-			h.t = t; h.idx = i; h.p = I;
-			lim = first_only ? -1.0f : t;
-			lim_hi = lim + fabsf(lim) * RT_PREFILTER_REL;
+		const bool meets = __builtin_amdgcn_ballot_w64(live && slab_hit(b0, make_float4(b0.w, b1.x, b1.y, 0.f), inv, oi, lim_hi)) != 0;
+		for (int m = 0; m < members && meets; m++) {
+			RT_PROF(wp, WP_TRI);
+			const c4ptr Tm = T.offset_floats(32 * m);
+			const int i = m == 0 ? __float_as_int(b1.w) : second;
+			const float4 N4 = Tm[0], P14 = Tm[1];
+			const vec3 nn = xyz(N4), p1 = xyz(P14);
+			const float t = dot(p1 - o, nn) / dot(d, nn);                           // Source.cpp:383
+			const bool visit = live && i != skip;                                   // Source.cpp:302
+			const bool cand = visit && (t > RT_EPS_BELOW) && (t < lim);             // Source.cpp:385, 391
+			if constexpr (COUNT) { lc.plane += visit; lc.point += visit && !(t < 0.0f); lc.edge += cand; }
+			if (__builtin_amdgcn_ballot_w64(cand) == 0) continue;
+			const float4 P24 = Tm[2], P34 = Tm[3], E0 = Tm[4], E1 = Tm[5], E2 = Tm[6];
+			const vec3 I = make3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);      // Source.cpp:389
+			const bool c0 = cand && (dot(nn, cross(xyz(E0), I - p1)) > 0.0f);       // Source.cpp:392
+			if constexpr (COUNT) lc.edge += c0;
+			if (__builtin_amdgcn_ballot_w64(c0) == 0) continue;
+			const bool c1 = c0 && (dot(nn, cross(xyz(E1), I - xyz(P24))) > 0.0f);   // Source.cpp:393
+			if constexpr (COUNT) lc.edge += c1;
+			if (__builtin_amdgcn_ballot_w64(c1) == 0) continue;
+			const bool c2 = c1 && (dot(nn, cross(xyz(E2), I - xyz(P34))) > 0.0f);   // Source.cpp:394
+			if (c2) {                                                               // Source.cpp:396
+				h.t = t; h.idx = i; h.p = I;
+				lim = first_only ? -1.0f : t;
+				lim_hi = lim + fabsf(lim) * RT_PREFILTER_REL;
+			}
 		}
+		j += members;
+		T = T.offset_floats(32 * members);
+		B = B.offset_floats(8 * members);
 	}
 }
 
@@ -709,6 +721,7 @@ __device__ __forceinline__ Hit trace_packet(const DevScene& sc, vec3 o, vec3 d, 
 		const unsigned int oct = __builtin_amdgcn_readlane(lane_oct, __builtin_ctzll(todo));
 		const bool mine = live && lane_oct == oct;
 		todo &= ~__builtin_amdgcn_ballot_w64(mine);
+		RT_PROF(wp, WP_TRACE);
 		const Hit hp = cast_ray_packet<false>(sc, (int)oct, o, d, inv, oi, skip, mine ? lim : -1.0f, KIND == RAY_SHADOW, lc, wp);
 		if (mine) h = hp;
 	}
@@ -1009,6 +1022,9 @@ __global__ void __launch_bounds__(256, ACCEL == 3 ? RT_MIN_WAVES_PACKET : RT_MIN
 	c4ptr lights;
 	lights.p = (const __attribute__((address_space(4))) v4f*)(unsigned long long)sc.lights;
 	WaveProf wp = {};
+#ifdef RT_PROFILE
+	wp.g = fp.counters;
+#endif
 	for (; tile < tile_end; tile++) {
 		const int x = tx * RT_TILE_W + lx, ly = ty * RT_TILE_H + lyi;
 		const bool inside = (x < fp.width) && (ly < fp.local_rows);
@@ -1086,6 +1102,10 @@ __global__ void __launch_bounds__(256, ACCEL == 3 ? RT_MIN_WAVES_PACKET : RT_MIN
 			out[0] = c.x; out[1] = c.y; out[2] = c.z;                        // Source.cpp:612-614
 		}
 	}
+#ifdef RT_PROFILE
+	if (fp.counters != nullptr && (threadIdx.x & 63) == 0)
+		for (int k = 0; k < 10; k++) atomicAdd(&fp.counters[k], (unsigned long long)wp.v[k]);
+#endif
 }
 
 // ---- castRay for a batch of rays (tests, tools) ----------------------------------------------

@@ -335,34 +335,58 @@ __global__ void __launch_bounds__(256) k_packet(const float4* __restrict__ nodes
 
 // 8. hoisted triangles (DevScene::hoist): their keys get the top bit, so they sort behind every
 //    triangle of the tree; their records are copied out in index order, followed by their padded
-//    boxes ordered near/far for each octant.
+//    boxes ordered near/far for each octant.  Two neighbours of the list whose boxes coincide (the two
+//    halves of a quad, Source.cpp:815-816: both span the quad's whole box) share ONE box test: the first
+//    carries the union and the triangle index of the second in its spare slot (-1: none), the second
+//    is stepped over by the traversals.
 __global__ void __launch_bounds__(64) k_hoist(const float4* __restrict__ planes, int stride, const int* __restrict__ idx, int k, float pad,
                                              u64* __restrict__ keys, float4* __restrict__ out) {
+	__shared__ float s_lo[RT_HOIST_MAX][3], s_hi[RT_HOIST_MAX][3];
+	__shared__ int s_second[RT_HOIST_MAX];       // triangle index of the partner that follows, or -1
 	const int j = threadIdx.x;
-	if (j >= k) return;
 	float4* boxes = out + (size_t)k * 8;
-	const int i = idx[j];
-	keys[i] = (1ull << 63) | (u64)(unsigned int)i;
-	float4* o = out + (size_t)j * 8;
-	o[0] = planes[PL_N * stride + i];
-	o[1] = planes[PL_P1 * stride + i];
-	o[2] = planes[PL_P2 * stride + i];
-	o[3] = planes[PL_P3 * stride + i];
-	o[4] = planes[PL_E0 * stride + i];
-	o[5] = planes[PL_E1 * stride + i];
-	o[6] = planes[PL_E2 * stride + i];
-	o[7] = make_float4(0.f, 0.f, 0.f, 0.f);
-	float lo[3], hi[3];
-	tri_box_padded(planes, stride, i, pad, lo, hi);
+	int i = 0;
+	if (j < k) {
+		i = idx[j];
+		keys[i] = (1ull << 63) | (u64)(unsigned int)i;
+		float4* o = out + (size_t)j * 8;
+		o[0] = planes[PL_N * stride + i];
+		o[1] = planes[PL_P1 * stride + i];
+		o[2] = planes[PL_P2 * stride + i];
+		o[3] = planes[PL_P3 * stride + i];
+		o[4] = planes[PL_E0 * stride + i];
+		o[5] = planes[PL_E1 * stride + i];
+		o[6] = planes[PL_E2 * stride + i];
+		o[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+		float lo[3], hi[3];
+		tri_box_padded(planes, stride, i, pad, lo, hi);
+		for (int a = 0; a < 3; a++) { s_lo[j][a] = lo[a]; s_hi[j][a] = hi[a]; }
+		s_second[j] = -1;
+	}
+	__syncthreads();
+	if (j == 0) {                                  // greedy pairing, left to right (k <= RT_HOIST_MAX)
+		for (int a = 0; a + 1 < k;) {
+			bool same = true;
+			for (int c = 0; c < 3; c++)
+				same = same && fabsf(s_lo[a][c] - s_lo[a + 1][c]) <= pad && fabsf(s_hi[a][c] - s_hi[a + 1][c]) <= pad;
+			if (same) {
+				for (int c = 0; c < 3; c++) { s_lo[a][c] = fminf(s_lo[a][c], s_lo[a + 1][c]); s_hi[a][c] = fmaxf(s_hi[a][c], s_hi[a + 1][c]); }
+				s_second[a] = idx[a + 1];
+				a += 2;
+			} else a++;
+		}
+	}
+	__syncthreads();
+	if (j >= k) return;
 	for (int oct = 0; oct < 8; oct++) {
 		float nr[3], fr[3];
 		for (int a = 0; a < 3; a++) {
 			const bool neg = (oct >> a) & 1;
-			nr[a] = neg ? hi[a] : lo[a];
-			fr[a] = neg ? lo[a] : hi[a];
+			nr[a] = neg ? s_hi[j][a] : s_lo[j][a];
+			fr[a] = neg ? s_lo[j][a] : s_hi[j][a];
 		}
 		boxes[((size_t)oct * k + j) * 2] = make_float4(nr[0], nr[1], nr[2], fr[0]);
-		boxes[((size_t)oct * k + j) * 2 + 1] = make_float4(fr[1], fr[2], 0.f, __int_as_float(i));
+		boxes[((size_t)oct * k + j) * 2 + 1] = make_float4(fr[1], fr[2], __int_as_float(s_second[j]), __int_as_float(i));
 	}
 }
 
