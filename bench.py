@@ -393,6 +393,7 @@ def run_tile_mode(args, api, torch, dist, rank, world, dev, on_gpu, name):
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in frames]
 
     def run(fs, timed):
+        done = []
         for i, f in enumerate(fs):
             buf = ex.shard(i)
             dst = buf if on_gpu else stage
@@ -403,8 +404,9 @@ def run_tile_mode(args, api, torch, dist, rank, world, dev, on_gpu, name):
                 evs[i][1].record()
             if not on_gpu:
                 buf.copy_(stage)
-            ex.submit(i)
-        ex.drain()
+            done += ex.submit(i)
+        done += ex.drain()
+        return done
 
     # the same frames by ONE GPU in one piece (rank 0, outside the timed region): the N=1 point of this workload
     single = None
@@ -431,6 +433,18 @@ def run_tile_mode(args, api, torch, dist, rank, world, dev, on_gpu, name):
     dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
+    # outside the timed region: one more frame through the same exchange, compared on rank 0 with the frame
+    # one GPU renders in one piece — the gathered framebuffer must be the reference's `data`, bit for bit
+    check = None
+    got = run([frames[-1]], False)
+    if rank == 0:
+        whole = torch.empty(H * W * 3, dtype=torch.float32, device="cuda")
+        sc.render_device(dev, w.cams[frames[-1]], w.trans[frames[-1]], W, H, D, api.STRICT, whole.data_ptr(), w.stream)
+        torch.cuda.synchronize()
+        full = got[-1][1]
+        same = torch.equal(full.to("cuda").view(torch.int32), whole.view(torch.int32))
+        check = "bit-identical to the single-GPU frame" if same else "DIFFERS from the single-GPU frame"
+        del whole
     kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)          # this rank's shard kernel, HIP events on the launch stream
     where = "cuda" if on_gpu else "cpu"
     t = torch.tensor([wall, kernel_ms], dtype=torch.float64, device=where)
@@ -459,7 +473,10 @@ def run_tile_mode(args, api, torch, dist, rank, world, dev, on_gpu, name):
                                  "tiles); non_render_ms_per_frame = wall per frame minus the slowest rank's kernel = exchange + "
                                  "de-interleave not hidden behind rendering" % (rows, H)},
             "single_gpu": single,
+            "gather_check": check,
         }
+        if check is not None and "DIFFERS" in check:
+            raise SystemExit("bench.py: the gathered frame differs from the single-GPU frame")
     w.close()
     return out
 

@@ -258,12 +258,12 @@ int         rt_device_count(void);
  * most RT_TILES_PER_WAVE_MAX.  Pixels do not depend on it. */
 #define RT_TILES_PER_WAVE_MAX 1024
 int         rt_scene_set_tiles_per_wave(rt_scene* s, int tiles);
-/* Tuning knob of one scene: which form of the render kernel brute-force and LBVH-packet launches use
- * (the per-lane LBVH traversal always runs in the state machine).  Pixels do not depend on it.
- * AUTO: lockstep up to max_bounces 2 (the reference's depth is 1), state machine beyond. */
+/* Tuning knob of one scene: which form of the render kernel its launches use.  Pixels do not depend
+ * on it.  AUTO is the lockstep form (measured faster than, or equal to, the state machine on every scene
+ * tried); the work-counting launches of rt_render_stats always run the state machine. */
 #define RT_KERNEL_AUTO          0
-#define RT_KERNEL_STATE_MACHINE 1   /* every lane its own stage, finished lanes refilled with new pixels: made for deep bounce loops */
-#define RT_KERNEL_LOCKSTEP      2   /* the 64 pixels of a tile stay in step: primary, mirror loop, one shadow ray per light */
+#define RT_KERNEL_STATE_MACHINE 1   /* every lane its own stage, finished lanes refilled with new pixels (ballot + prefix ranks) */
+#define RT_KERNEL_LOCKSTEP      2   /* the 64 pixels of a tile stay in step: primary ray, mirror loop, one shadow ray per light */
 int         rt_scene_set_kernel(rt_scene* s, int kind);
 /* Tuning knob of one scene: how its LBVH is traversed.  RT_TRAVERSAL_AUTO lets each launch choose
  * by the coherence of an 8x8 tile of rays against the scene's triangles; both give

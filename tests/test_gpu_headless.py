@@ -46,8 +46,41 @@ def test_headless_walk_equals_oracle(tmp_path, oracle):
     assert np.array_equal(_bits(got), _bits(want))
     assert not np.array_equal(_bits(want), _bits(oracle.render_desc(desc)))      # the camera really moved
 
+    # the same walk through the pipelined hand-off (rt_render_async into two pinned frames) and with a loaded model
+    raw2 = tmp_path / "out_async.f32"
+    res = subprocess.run([EXE, "--scene", str(scene), "--walk", str(walk), "--raw", str(raw2), "--async"], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    assert np.array_equal(_bits(np.fromfile(raw2, dtype=np.float32).reshape(desc.height, desc.width, 3)), _bits(want))
+    bad = subprocess.run([EXE, "--scene", str(scene), "--size", "-5", "64"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 2 and "not usable" in bad.stderr                     # (used to abort on the allocation)
+
     # Image.txt: P3, top row first, GL unorm quantisation
     tok = txt.read_text().split()
     assert tok[:4] == ["P3", str(desc.width), str(desc.height), "255"]
     px = np.array(tok[4:], dtype=np.int64).reshape(desc.height, desc.width, 3)
     assert np.array_equal(px[::-1], oracle.quantize(want).astype(np.int64))
+
+
+def test_bench_row_tile_mode_two_ranks_on_one_gpu():
+    """The N > 1 default of bench.py — BASELINE config 5: interleaved 16-row tiles of 7680x4320 frames,
+    rendered by rt_render_tiles_device on every rank and gathered on rank 0 by the pipelined exchange —
+    rehearsed with two ranks sharing this one GPU (gloo carries the shards; on a node it is RCCL): the
+    line must carry the strong-scaling fields and the gathered frame must be the single-GPU frame."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["parallelism"] == "row tiles x2"
+    assert d["config"]["width"] == 7680 and d["config"]["height"] == 4320
+    assert d["gather_check"].startswith("bit-identical")
+    assert d["roofline"]["frac"] > 0 and d["roofline"]["kernel_ms"] > 0 and d["exchange"]["shard_MB"] > 190
+    assert d["single_gpu"]["ms_per_frame"] > 0 and d["value"] > 0

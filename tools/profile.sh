@@ -1,54 +1,68 @@
 #!/bin/bash
-# tools/profile.sh <round-tag> — run on the GPU box (gpurun): collects, for the default bench
-# command, (1) the rocprofv3 kernel-trace summary, (2) HBM traffic counters in separate --pmc
-# passes (FETCH_SIZE and WRITE_SIZE do not fit one pass), (3) SQ instruction counters.
-# Writes summaries under gpurun_out/profiles_<tag>/; copy what should be judged into profiles/.
-tag=${1:-r01}
+# tools/profile.sh <round-tag> — run on the GPU box (gpurun).  For the headline workload (room800) and the
+# LBVH workload (spheres800) it collects, each in a run of its own:
+#   (1) rocprofv3 --kernel-trace --stats of the bench command            -> <tag>_<w>_kernel_stats.csv
+#   (2) HBM traffic: FETCH_SIZE and WRITE_SIZE in separate --pmc passes   -> traffic.json (bytes per launch)
+#   (3) SQ instruction and wait counters                                  -> <tag>_<w>_pmc.json
+#   (4) the VALU instruction mix (two passes)                             -> issued.json (issued VALU TFLOP/s)
+# Summaries go to gpurun_out/profiles_<tag>/; copy what should be judged into profiles/.
+tag=${1:-r02}
 out=gpurun_out/profiles_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-args="--steps 4 --warmup 1 --no-cpu --no-configs"
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o room800 -- python3 bench.py $args > $out/bench_under_trace.json 2> $out/trace.err || exit 1
-cp $out/trace/room800_kernel_stats.csv $out/${tag}_room800_kernel_stats.csv
-for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE"; do
-  name=$(echo $pass | cut -d' ' -f1)
-  timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d $out/pmc_$name -o p -- python3 bench.py --steps 4 --warmup 1 --no-cpu --no-configs > /dev/null 2> $out/pmc_$name.err || exit 1
+for w in room800 spheres800; do
+  args="--steps 8 --warmup 2 --no-cpu --no-configs --workload $w"
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_$w -o $w -- python3 bench.py $args > $out/${tag}_${w}_bench_under_rocprof.json 2> $out/trace_$w.err || exit 1
+  cp $out/trace_$w/${w}_kernel_stats.csv $out/${tag}_${w}_kernel_stats.csv
+  i=0
+  for pass in "FETCH_SIZE" "WRITE_SIZE" \
+              "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
+              "SQ_WAVES SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_SMEM" \
+              "SQ_WAVES SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_BRANCH SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" \
+              "GRBM_GUI_ACTIVE"; do
+    i=$((i+1))
+    timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d $out/pmc_${w}_$i -o p -- python3 bench.py $args > $out/pmc_${w}_$i.json 2> $out/pmc_${w}_$i.err || exit 1
+  done
 done
 python3 - $out $tag <<'PY'
 import csv, sys, json, collections, glob, os
 out, tag = sys.argv[1], sys.argv[2]
-acc = collections.defaultdict(list)
-for f in glob.glob(os.path.join(out, "pmc_*", "p_counter_collection.csv")):
-    for r in csv.DictReader(open(f)):
-        if "render_kernel<0, false>" in r["Kernel_Name"]:
-            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-summ = {k: sum(v) / len(v) for k, v in acc.items()}
-summ["_launches_sampled"] = {k: len(v) for k, v in acc.items()}
-# FETCH_SIZE / WRITE_SIZE are in KiB; MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads half the bytes of a
-# wide coalesced read stream (uncalibrated for other widths); WRITE_SIZE is exact for 16-B stores.
-fetch_kib, write_kib = summ.get("FETCH_SIZE", 0.0), summ.get("WRITE_SIZE", 0.0)
-summ["hbm_bytes_per_launch"] = {"fetch_raw": fetch_kib * 1024, "fetch_x2_gfx950": 2 * fetch_kib * 1024, "write": write_kib * 1024,
-                                "total_corrected": (2 * fetch_kib + write_kib) * 1024}
-json.dump(summ, open(os.path.join(out, tag + "_room800_pmc.json"), "w"), indent=1)
-print(json.dumps(summ, indent=1))
+traffic, issued = {}, {}
+for w, kern in (("room800", "render_lockstep_kernel<0>"), ("spheres800", "render_lockstep_kernel<3>")):
+    acc = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(out, "pmc_%s_*" % w, "p_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if kern in r["Kernel_Name"]:
+                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    summ = {k: sum(v) / len(v) for k, v in acc.items()}
+    summ["_kernel"] = kern
+    summ["_launches_sampled"] = {k: len(v) for k, v in acc.items()}
+    # kernel time of the un-counted bench run under the kernel trace (same command)
+    ns = None
+    for r in csv.DictReader(open(os.path.join(out, "%s_%s_kernel_stats.csv" % (tag, w)))):
+        if kern in r["Name"]:
+            ns = float(r["AverageNs"])
+    summ["kernel_trace_average_ns"] = ns
+    # FETCH_SIZE / WRITE_SIZE are in KiB; MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads half the bytes of a
+    # wide coalesced read stream (uncalibrated for other widths); WRITE_SIZE is exact for 16-B stores.
+    fetch_kib, write_kib = summ.get("FETCH_SIZE", 0.0), summ.get("WRITE_SIZE", 0.0)
+    summ["hbm_bytes_per_launch"] = {"fetch_raw": fetch_kib * 1024, "fetch_x2_gfx950": 2 * fetch_kib * 1024, "write": write_kib * 1024,
+                                    "total_corrected": (2 * fetch_kib + write_kib) * 1024}
+    traffic[w] = summ["hbm_bytes_per_launch"]["total_corrected"]
+    wv = summ.get("SQ_WAVES", 1.0)
+    summ["per_wave"] = {k: summ[k] / wv for k in summ if k.startswith("SQ_INSTS")}
+    # issued VALU FLOPs: one per lane for add/mul/transcendental, two for fma, 64 lanes per wave instruction (an upper
+    # bound: masked-off lanes are counted) — the secondary figure SURVEY 8d asks for beside the algorithmic one
+    fl = 64.0 * (summ.get("SQ_INSTS_VALU_ADD_F32", 0) + summ.get("SQ_INSTS_VALU_MUL_F32", 0) + 2 * summ.get("SQ_INSTS_VALU_FMA_F32", 0)
+                 + summ.get("SQ_INSTS_VALU_TRANS_F32", 0) + summ.get("SQ_INSTS_VALU_ADD_F64", 0) + summ.get("SQ_INSTS_VALU_MUL_F64", 0)
+                 + 2 * summ.get("SQ_INSTS_VALU_FMA_F64", 0))
+    summ["issued_valu_flops_per_launch"] = fl
+    if ns:
+        issued[w] = fl / (ns * 1e-9) / 1e12
+        summ["issued_valu_tflops"] = issued[w]
+    json.dump(summ, open(os.path.join(out, "%s_%s_pmc.json" % (tag, w)), "w"), indent=1)
+    print(w, json.dumps({k: summ[k] for k in ("kernel_trace_average_ns", "hbm_bytes_per_launch", "per_wave", "issued_valu_tflops") if k in summ}, indent=1))
+json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+json.dump(issued, open(os.path.join(out, "issued.json"), "w"), indent=1)
 PY
-cat $out/${tag}_room800_kernel_stats.csv
-
-# ---- LBVH workload (config 4): kernel trace + SQ counters ----------------------------------------
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_lbvh -o spheres800 -- python3 bench.py --steps 4 --warmup 1 --no-cpu --no-configs --workload spheres800 > $out/${tag}_spheres800_bench_under_rocprof.json 2> $out/trace_lbvh.err || exit 1
-cp $out/trace_lbvh/spheres800_kernel_stats.csv $out/${tag}_spheres800_kernel_stats.csv
-timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $out/pmc_lbvh -o p -- python3 bench.py --steps 4 --warmup 1 --no-cpu --no-configs --workload spheres800 > /dev/null 2> $out/pmc_lbvh.err || exit 1
-python3 - $out $tag <<'PY'
-import csv, sys, json, collections, os
-out, tag = sys.argv[1], sys.argv[2]
-acc = collections.defaultdict(list)
-for r in csv.DictReader(open(os.path.join(out, "pmc_lbvh", "p_counter_collection.csv"))):
-    if "render_kernel<2, false>" in r["Kernel_Name"] or "render_kernel<3, false>" in r["Kernel_Name"]:   # per-lane or packet traversal
-        acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-summ = {k: sum(v) / len(v) for k, v in acc.items()}
-w = summ.get("SQ_WAVES", 1.0)
-summ["per_wave"] = {k: summ[k] / w for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS") if k in summ}
-json.dump(summ, open(os.path.join(out, tag + "_spheres800_pmc.json"), "w"), indent=1)
-print(json.dumps(summ, indent=1))
-PY
-cat $out/${tag}_spheres800_kernel_stats.csv
+for w in room800 spheres800; do cat $out/${tag}_${w}_kernel_stats.csv; done
