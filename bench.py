@@ -227,13 +227,14 @@ def roofline_of(flops_per_launch, kernel_ms, fpl, launches, workload):
                     "the kernel really executes per second (PMC pass under profiles/), secondary"}
 
 
-def side_config(api, torch, name, dev, args, launches=3):
-    """One of the other BASELINE configs, measured on its own: `launches` timed launches after one warm-up."""
+def side_config(api, torch, name, dev, args, launches=6):
+    """One of the other BASELINE configs, measured on its own: `launches` timed launches after two warm-up launches."""
     w = Workload(api, torch, name, dev, args)
     try:
         batches = [w.batch(s) for s in range(launches)]
         w.count([f for b in batches for f in b])
         w.launch(batches[0])
+        w.launch(batches[1])
         wall, kernel_ms = w.timed_launches(batches)
         frames = launches * w.fpl
         rays = float(sum(w.rays_of[f] for b in batches for f in b))
