@@ -10,7 +10,12 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdint>
 #include <mutex>
+
+#ifndef RT_BLIT_BLOCKS
+#define RT_BLIT_BLOCKS 256
+#endif
 
 namespace rt {
 
@@ -596,6 +601,18 @@ int rt_render_multi(rt_scene* s, const int* devices, int n_devices, const float 
 
 // ---- the hand-off to the viewer, pipelined (Source.cpp:1270) -------------------------------------
 
+// Frame copy into pinned host memory by the shader cores (16-byte coalesced stores over PCIe) instead of a copy
+// engine: measured per 7.68 MB frame, pipelined, 0.29 ms with hipMemcpyAsync (26 GB/s) against 0.174 ms with this
+// kernel on 256 workgroups (44 GB/s; 64 workgroups 0.198, 1024 the same as 256).
+__global__ void __launch_bounds__(256) blit_frame_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n_floats) {
+	const size_t n4 = n_floats / 4;
+	const size_t stride = (size_t)gridDim.x * blockDim.x;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+		((float4*)dst)[i] = ((const float4*)src)[i];
+	for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_floats; i += stride)
+		dst[i] = src[i];
+}
+
 float* rt_frame_alloc(size_t n_floats) {
 	void* p = nullptr;
 	hipError_t e = hipHostMalloc(&p, (n_floats > 0 ? n_floats : 1) * sizeof(float), hipHostMallocDefault);
@@ -642,7 +659,20 @@ int rt_render_async(rt_scene* s, const float cam_pos[3], const float trans16[16]
 	if (rc != RT_OK) return rc;
 	RT_HIP(hipEventRecord(d->rendered[slot], d->render_stream));
 	RT_HIP(hipStreamWaitEvent(d->copy_stream, d->rendered[slot], 0));
-	RT_HIP(hipMemcpyAsync(out_rgb, d->aframe[slot], bytes, hipMemcpyDeviceToHost, d->copy_stream));
+	{
+		// a pinned destination (rt_frame_alloc) is written by a copy kernel; pageable memory goes through the runtime
+		hipPointerAttribute_t attr;
+		float* dev_view = nullptr;
+		if (hipPointerGetAttributes(&attr, out_rgb) == hipSuccess && attr.type == hipMemoryTypeHost && attr.devicePointer && ((uintptr_t)attr.devicePointer & 15u) == 0)
+			dev_view = (float*)attr.devicePointer;
+		(void)hipGetLastError();
+		if (dev_view) {
+			hipLaunchKernelGGL(blit_frame_kernel, dim3(RT_BLIT_BLOCKS), dim3(256), 0, d->copy_stream, (const float*)d->aframe[slot], dev_view, bytes / sizeof(float));
+			RT_HIP(hipGetLastError());
+		} else {
+			RT_HIP(hipMemcpyAsync(out_rgb, d->aframe[slot], bytes, hipMemcpyDeviceToHost, d->copy_stream));
+		}
+	}
 	RT_HIP(hipEventRecord(d->copied[slot], d->copy_stream));
 	d->ticket_of_slot[slot] = ticket;
 	s->next_ticket = ticket + 1;
