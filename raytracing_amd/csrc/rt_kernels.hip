@@ -568,8 +568,9 @@ __device__ __forceinline__ void flush_counters(unsigned long long* g, const unsi
 }
 
 // ---- the render kernel -----------------------------------------------------------------------
-// ACCEL 0: brute force with the scene in LDS; 1: brute force reading the global planes (scenes
-// too large for LDS); 2: LBVH traversal (rt_lbvh.inl).
+// ACCEL 0: brute force, the scene read through the scalar cache, with a per-workgroup LDS table of the primary
+// rays' numerators (scenes up to RT_LDS_MAX_TRIS triangles); 1: the same without that table (forced brute force on
+// larger scenes); 2: LBVH, per-lane walk of the 4-wide tree (rt_lbvh_trav.inl); 3: LBVH, wave-uniform packet walk.
 // `shadow`: the lane's ray is a shadow ray towards a light at distance `dist`.
 // `all_primary` (wave-uniform): every live lane holds a primary ray from the camera.
 template <int ACCEL, bool COUNT>
