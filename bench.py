@@ -74,6 +74,7 @@ def parse():
     ap.add_argument("--size", type=int, nargs=2, default=None, help="override the workload's frame size (experiments)")
     ap.add_argument("--traversal", default="auto", choices=["auto", "per-lane", "packet"])
     ap.add_argument("--kernel", default="auto", choices=["auto", "state-machine", "lockstep"], help="form of the brute-force render kernel (rt_scene_set_kernel)")
+    ap.add_argument("--build", default="sah", choices=["fast", "sah"], help="how LBVH commits build their tree (rt_scene_set_build)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo lets several ranks share one GPU to rehearse the N>1 path")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -151,6 +152,8 @@ class Workload:
         self.scene = api.Scene.from_desc(desc)
         self.scene.set_traversal({"auto": api.TRAVERSAL_AUTO, "per-lane": api.TRAVERSAL_PER_LANE, "packet": api.TRAVERSAL_PACKET}[args.traversal])
         self.scene.set_kernel({"auto": api.KERNEL_AUTO, "state-machine": api.KERNEL_STATE_MACHINE, "lockstep": api.KERNEL_LOCKSTEP}[args.kernel])
+        self.scene.set_build({"fast": api.BUILD_FAST, "sah": api.BUILD_SAH}[args.build])
+        self.build = args.build if accel_name == "lbvh" else None
         if args.tiles_per_wave:
             self.scene.set_tiles_per_wave(args.tiles_per_wave)
         self.scene.commit(dev, api.ACCEL_LBVH if accel_name == "lbvh" else api.ACCEL_BRUTE)
@@ -246,6 +249,7 @@ def side_config(api, torch, name, dev, args, launches=6):
                "roofline_frac": flops / launches / (kernel_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
                "flops_per_ray": flops / rays}
         if w.accel_name == "lbvh":
+            out["build"] = w.build
             out["build_ms"] = w.scene.build_ms(dev)
             out["bvh_depth"] = list(w.scene.bvh_depth(dev))
         return out
@@ -350,7 +354,7 @@ def run_frames_mode(args, api, torch, dist, rank, world, dev, on_gpu, name):
             "value": total_rays / wall / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": wall / args.steps * 1e3, "frames_per_step": fpl, "ms_per_frame": wall / (args.steps * fpl) * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": w.label, "accel": w.accel_name, "traversal": w.traversal(), "width": w.W, "height": w.H,
+            "config": {"workload": w.label, "accel": w.accel_name, "traversal": w.traversal(), "build": w.build, "width": w.W, "height": w.H,
                        "max_bounces": w.D, "triangles": w.scene.n_triangles, "lights": w.scene.n_lights, "frames_per_step": fpl,
                        "frames": "64-pose camera path (rt_camera_path: look right + forward, 16 ms frames); step s of rank r = one launch "
                                  "over the %d consecutive poses from ((s*N + r)*%d) mod 64" % (fpl, fpl),

@@ -265,6 +265,17 @@ int         rt_scene_set_tiles_per_wave(rt_scene* s, int tiles);
 #define RT_KERNEL_STATE_MACHINE 1   /* every lane its own stage, finished lanes refilled with new pixels (ballot + prefix ranks) */
 #define RT_KERNEL_LOCKSTEP      2   /* the 64 pixels of a tile stay in step: primary ray, mirror loop, one shadow ray per light */
 int         rt_scene_set_kernel(rt_scene* s, int kind);
+/* Tuning knob of one scene: how the tree of an RT_ACCEL_LBVH commit is built (takes effect at the next
+ * rt_scene_commit; committed trees of the scene become stale).  Pixels do not depend on it.
+ * SAH (the default): the topology by a binned surface-area heuristic on host threads, boxes and the
+ * derived records on the GPU; about 15 ms per 100k triangles on 16 cores, for a tree rays cross in
+ * fewer nodes (100k-triangle scene: 14 % less time per frame walked per lane, 8 % by packets) — a
+ * scene committed once and rendered for many frames, which is the reference's use (Src:815-880 builds the
+ * scene once in main).  FAST: Morton codes, radix sort and Karras' construction on the GPU, half a
+ * millisecond per 100k triangles — for scenes that are re-committed every few frames. */
+#define RT_BUILD_FAST 0
+#define RT_BUILD_SAH  1
+int         rt_scene_set_build(rt_scene* s, int quality);
 /* Tuning knob of one scene: how its LBVH is traversed.  RT_TRAVERSAL_AUTO lets each launch choose
  * by the coherence of an 8x8 tile of rays against the scene's triangles; both give
  * the reference's bits.  A preference: a tree too deep for the per-lane stack (rt_scene_bvh_depth)

@@ -23,6 +23,7 @@ RT_OK = 0
 ACCEL_AUTO, ACCEL_BRUTE, ACCEL_LBVH = 0, 1, 2
 TRAVERSAL_AUTO, TRAVERSAL_PER_LANE, TRAVERSAL_PACKET = 0, 1, 2
 KERNEL_AUTO, KERNEL_STATE_MACHINE, KERNEL_LOCKSTEP = 0, 1, 2
+BUILD_FAST, BUILD_SAH = 0, 1
 STRICT = 0            # RT_RENDER_STRICT: the only render mode (bit-identical frames)
 STACK_LIMIT = 64      # RT_STACK_LIMIT
 NOALLOC_MAX_RAYS = 16384
@@ -40,7 +41,7 @@ SYMBOLS = (
     "rt_camera_translate", "rt_camera_frame_time", "rt_camera_step", "rt_camera_path", "rt_render", "rt_render_device",
     "rt_render_frames_device", "rt_render_tiles_device", "rt_shard_rows", "rt_render_stats", "rt_render_multi", "rt_cast_rays",
     "rt_render_async", "rt_render_wait", "rt_frame_alloc", "rt_frame_free", "rt_cast_rays_noalloc",
-    "rt_device_count", "rt_scene_set_tiles_per_wave", "rt_scene_set_traversal", "rt_scene_set_kernel", "rt_scene_traversal", "rt_last_error", "rt_version",
+    "rt_device_count", "rt_scene_set_tiles_per_wave", "rt_scene_set_traversal", "rt_scene_set_kernel", "rt_scene_set_build", "rt_scene_traversal", "rt_last_error", "rt_version",
 )
 
 
@@ -149,6 +150,7 @@ def lib():
     L.rt_scene_set_tiles_per_wave.argtypes = [vp, ci]
     L.rt_scene_set_traversal.argtypes = [vp, ci]
     L.rt_scene_set_kernel.argtypes = [vp, ci]
+    L.rt_scene_set_build.argtypes = [vp, ci]
     L.rt_scene_bvh_depth.argtypes = [vp, ci, C.POINTER(ci), C.POINTER(ci)]
     L.rt_render_async.argtypes = [vp, _fp, _fp, ci, ci, ci, ci, vp]
     L.rt_render_wait.argtypes = [vp, ci]
@@ -411,6 +413,12 @@ class Scene:
     def set_kernel(self, kind: int) -> "Scene":
         """Which form of the render kernel brute-force launches use (rt_scene_set_kernel)."""
         _check(lib().rt_scene_set_kernel(self._h, int(kind)))
+        return self
+
+    def set_build(self, quality: int) -> "Scene":
+        """How the tree of the next LBVH commit is built: BUILD_FAST (Morton/Karras on the GPU) or BUILD_SAH
+        (binned surface-area heuristic on the host; rt_scene_set_build)."""
+        _check(lib().rt_scene_set_build(self._h, int(quality)))
         return self
 
     def set_tiles_per_wave(self, tiles: int) -> "Scene":

@@ -247,6 +247,16 @@ int rt_scene_set_kernel(rt_scene* s, int kind) {
 	return RT_OK;
 }
 
+int rt_scene_set_build(rt_scene* s, int quality) {
+	if (!s) { set_error("rt_scene_set_build: NULL scene"); return RT_ERR_INVALID; }
+	if (quality != RT_BUILD_FAST && quality != RT_BUILD_SAH) { set_error("rt_scene_set_build: unknown quality %d", quality); return RT_ERR_INVALID; }
+	if (s->build != quality) {
+		s->build = quality;
+		for (auto& kv : s->dev) if (kv.second.accel == RT_ACCEL_LBVH) kv.second.valid = false;      // trees are rebuilt at the next commit
+	}
+	return RT_OK;
+}
+
 int rt_scene_bvh_depth(const rt_scene* s, int device, int* binary_depth, int* wide_depth) {
 	if (!s || !binary_depth || !wide_depth) { set_error("rt_scene_bvh_depth: NULL argument"); return RT_ERR_INVALID; }
 	auto it = s->dev.find(device);

@@ -176,6 +176,7 @@ struct rt_scene {
 	int tiles_per_wave = 0;               // rt_scene_set_tiles_per_wave (0: the launcher's rule)
 	long long next_ticket = 0;            // rt_render_async
 	int kernel_kind = RT_KERNEL_AUTO;     // rt_scene_set_kernel
+	int build = RT_BUILD_SAH;             // rt_scene_set_build (takes effect at the next LBVH commit)
 	int uv_w = -1, uv_h = -1;             // frame size the division-free u, v were last checked for (rt_api.cpp fill_frame)
 	bool uv_fast = false;
 };
@@ -185,6 +186,10 @@ namespace rt {
 void set_error(const char* fmt, ...);
 int hip_fail(hipError_t e, const char* what);
 #define RT_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return rt::hip_fail(e_, #call); } while (0)
+
+// rt_sah.cpp
+void sah_topology(const std::vector<float>& tris, const std::vector<int>& hoisted, int nt, std::vector<unsigned long long>& keys,
+                  std::vector<int>& child, std::vector<int>& parent_int, std::vector<int>& parent_leaf);
 
 // rt_scene.cpp
 void triangle_record(vec3 p1, vec3 p2, vec3 p3, vec3 color, float shin, float* out28);

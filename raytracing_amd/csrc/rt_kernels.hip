@@ -1194,7 +1194,7 @@ static bool use_packets_cols(const DevScene& sc, const float col0[3], const floa
 	const float du = sqrtf(col0[0] * col0[0] + col0[1] * col0[1] + col0[2] * col0[2]) / (float)(width > 0 ? width : 1);
 	const float dv = sqrtf(col1[0] * col1[0] + col1[1] * col1[1] + col1[2] * col1[2]) / (float)(height > 0 ? height : 1);
 	const float footprint = 8.0f * 0.5f * (du + dv) * sc.packet_scale;
-	return footprint < 5.0f;
+	return footprint < 4.0f;
 }
 
 static int pick_tiles_per_wave(int accel, long long tiles) {

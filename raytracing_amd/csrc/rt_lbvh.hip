@@ -35,6 +35,7 @@
 
 #include <cstring>
 #include <cstdlib>
+#include <chrono>
 #include <rocprim/device/device_radix_sort.hpp>
 
 namespace rt {
@@ -442,6 +443,7 @@ int tree_depth(const std::vector<int>& refs, int width, int n_nodes) {
 	return depth;
 }
 
+
 template <typename T>
 int dev_alloc(T** p, size_t count) {
 	hipError_t e = hipMalloc((void**)p, count * sizeof(T));
@@ -481,6 +483,7 @@ int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 	pick_hoisted(s->tris, d.bb_lo, d.bb_hi, hoisted);
 	const int nh = (int)hoisted.size();
 	const int nt = n - nh;                       // triangles in the tree
+	const bool sah = s->build == RT_BUILD_SAH;
 	const size_t hoist_float4s = (size_t)nh * (8 + 8 * 2);   // records, then 8 octants of boxes
 	int* hoist_idx = nullptr;
 	float4* hoist = nullptr;
@@ -550,6 +553,22 @@ int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 	const unsigned int blocks_n = (unsigned int)((n + 255) / 256);
 	const unsigned int blocks_t = (unsigned int)((nt + 255) / 256);
 
+	float host_ms = 0.f;
+	std::vector<u64> h_keys;
+	std::vector<int> h_child, h_pint, h_pleaf, h_nodes;
+	if (sah) {
+		const auto t0 = std::chrono::steady_clock::now();
+		try { sah_topology(s->tris, hoisted, nt, h_keys, h_child, h_pint, h_pleaf); }
+		catch (...) { set_error("LBVH (SAH build): out of host memory or threads"); rc = RT_ERR_NOMEM; }
+		LB_TRY(rc);
+		// whole nodes with only the child references set (k_refit fills the boxes): one contiguous upload
+		try {
+			h_nodes.assign((size_t)(nt - 1) * 16, 0);
+			for (size_t i = 0; i < (size_t)(nt - 1); i++) { h_nodes[i * 16 + 12] = h_child[i * 2]; h_nodes[i * 16 + 13] = h_child[i * 2 + 1]; }
+		} catch (...) { set_error("LBVH (SAH build): out of host memory"); rc = RT_ERR_NOMEM; }
+		LB_TRY(rc);
+		host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+	}
 	LB_HIP(hipEventRecord(e0, stream));
 	LB_HIP(hipMemsetAsync(flags, 0, (size_t)n * sizeof(unsigned int), stream));
 	LB_HIP(hipMemsetAsync(nodes, 0, (size_t)(nt - 1) * 4 * sizeof(float4), stream));
@@ -559,11 +578,21 @@ int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 		hipLaunchKernelGGL(k_hoist, dim3(1), dim3(64), 0, stream, planes, d.stride, (const int*)hoist_idx, nh, pad, keys, hoist);
 		LB_HIP(hipGetLastError());
 	}
-	LB_HIP(rocprim::radix_sort_keys(temp, temp_bytes, keys, keys_sorted, (size_t)n, 0, key_bits, stream));
-	// (the hoisted keys sorted to the tail: the tree is built over the first nt)
-	hipLaunchKernelGGL(k_karras, dim3(blocks_t), dim3(256), 0, stream, keys_sorted, nt, index_mask, nodes, parent_int, parent_leaf);
-	LB_HIP(hipGetLastError());
-	hipLaunchKernelGGL(k_refit, dim3(blocks_t), dim3(256), 0, stream, planes, d.stride, nt, keys_sorted, index_mask, (float*)nodes,
+	unsigned int leaf_mask = index_mask;
+	if (sah) {
+		// the host's topology in place of sort + k_karras: leaf order, child references (the fourth float4 of a node), parent links
+		LB_HIP(hipMemcpyAsync(keys_sorted, h_keys.data(), (size_t)nt * sizeof(u64), hipMemcpyHostToDevice, stream));
+		LB_HIP(hipMemcpyAsync(nodes, h_nodes.data(), (size_t)(nt - 1) * 64, hipMemcpyHostToDevice, stream));
+		LB_HIP(hipMemcpyAsync(parent_int, h_pint.data(), (size_t)nt * sizeof(int), hipMemcpyHostToDevice, stream));
+		LB_HIP(hipMemcpyAsync(parent_leaf, h_pleaf.data(), (size_t)nt * sizeof(int), hipMemcpyHostToDevice, stream));
+		leaf_mask = 0xffffffffu;
+	} else {
+		LB_HIP(rocprim::radix_sort_keys(temp, temp_bytes, keys, keys_sorted, (size_t)n, 0, key_bits, stream));
+		// (the hoisted keys sorted to the tail: the tree is built over the first nt)
+		hipLaunchKernelGGL(k_karras, dim3(blocks_t), dim3(256), 0, stream, keys_sorted, nt, index_mask, nodes, parent_int, parent_leaf);
+		LB_HIP(hipGetLastError());
+	}
+	hipLaunchKernelGGL(k_refit, dim3(blocks_t), dim3(256), 0, stream, planes, d.stride, nt, keys_sorted, leaf_mask, (float*)nodes,
 	                   parent_int, parent_leaf, flags, pad);
 	LB_HIP(hipGetLastError());
 	hipLaunchKernelGGL(k_collapse4, dim3(blocks_t), dim3(256), 0, stream, (const float4*)nodes, nt - 1, nodes4);
@@ -595,16 +624,18 @@ int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 	// (16 B of every 64-byte node): what the traversal stacks have to hold (rt_lbvh_trav.inl header).
 	int depth2 = 0, depth4 = 0;
 	try {
-		std::vector<int> refs((size_t)(nt - 1) * 4);
-		LB_HIP(hipMemcpy2D(refs.data(), 16, (const char*)nodes + 48, 64, 16, (size_t)(nt - 1), hipMemcpyDeviceToHost));
-		for (size_t i = 0; i < (size_t)(nt - 1); i++) { refs[i * 2] = refs[i * 4]; refs[i * 2 + 1] = refs[i * 4 + 1]; }   // (left, right, 0, 0) -> pairs
+		// (whole arrays in one copy each: a strided hipMemcpy2D of 16 bytes per node takes a second per 100k nodes)
+		std::vector<int> all((size_t)(nt - 1) * 16), refs((size_t)(nt - 1) * 4);
+		LB_HIP(hipMemcpy(all.data(), nodes, (size_t)(nt - 1) * 64, hipMemcpyDeviceToHost));
+		for (size_t i = 0; i < (size_t)(nt - 1); i++) { refs[i * 2] = all[i * 16 + 12]; refs[i * 2 + 1] = all[i * 16 + 13]; }   // q3 = (left, right, 0, 0)
 		depth2 = tree_depth(refs, 2, nt - 1);
-		LB_HIP(hipMemcpy2D(refs.data(), 16, (const char*)nodes4 + 16, 64, 16, (size_t)(nt - 1), hipMemcpyDeviceToHost));
-		for (int& r : refs) if (r == RT_BVH4_EMPTY) r = -1;
+		LB_HIP(hipMemcpy(all.data(), nodes4, (size_t)(nt - 1) * 64, hipMemcpyDeviceToHost));
+		for (size_t i = 0; i < (size_t)(nt - 1); i++)
+			for (int c = 0; c < 4; c++) { const int r = all[i * 16 + 4 + c]; refs[i * 4 + c] = r == RT_BVH4_EMPTY ? -1 : r; }       // w1 = the 4 child references
 		depth4 = tree_depth(refs, 4, nt - 1);
 	} catch (...) { set_error("LBVH: out of host memory measuring the tree"); rc = RT_ERR_NOMEM; }
 	if (rc == RT_OK && (depth2 < 1 || depth4 < 1 || depth2 > 63)) {
-		// (63-bit unique keys bound the Karras tree at 63 levels: the packet stack has 64 entries)
+		// (63-bit unique keys bound the Karras tree at 63 levels, RT_SAH_MEDIAN_DEPTH the SAH tree: the packet stack has 64 entries)
 		set_error("LBVH: malformed tree (binary depth %d, 4-wide depth %d)", depth2, depth4);
 		rc = RT_ERR_DEVICE;
 	}
@@ -633,7 +664,7 @@ int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 	d.bvh_depth = depth2;
 	d.bvh4_depth = depth4;
 	d.per_lane_ok = 3 * depth4 <= RT_STACK_LIMIT;
-	d.build_ms = ms;
+	d.build_ms = ms + host_ms;
 	return RT_OK;
 }
 

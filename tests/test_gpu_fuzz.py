@@ -1,7 +1,7 @@
 """Differential fuzz of the render paths: random triangle soups (with needles and slivers) and 'walls and
 crumbs' scenes (a few scene-sized triangles over many tiny ones — the ones lbvh_build hoists), random frame
 sizes, bounce depths, light counts and extents from 1e-3 to 1e4.  Every path of the library — brute force and
-the LBVH walked per lane and by packets, each in the lockstep and the state-machine kernel — must give the
+the LBVH (both tree builds) walked per lane and by packets, each in the lockstep and the state-machine kernel — must give the
 oracle's frame bit for bit (the oracle restates Source.cpp:642-780; tests/test_oracle_golden.py pins it).
 scripts/fuzz_paths.py runs the same cases by the thousand without the oracle."""
 import numpy as np
@@ -45,13 +45,15 @@ def render_all_paths(desc):
         for kind, kname in ((api.KERNEL_LOCKSTEP, "lockstep"), (api.KERNEL_STATE_MACHINE, "state machine")):
             sc.set_kernel(kind)
             frames.append(("brute/" + kname, sc.render(desc.cam_pos, tr, desc.width, desc.height, desc.depth)))
-        sc.commit(0, api.ACCEL_LBVH)
-        hoisted = int(sc.hoisted(0).size)
-        for mode, mname in ((api.TRAVERSAL_PER_LANE, "per lane"), (api.TRAVERSAL_PACKET, "packets")):
-            sc.set_traversal(mode)
-            for kind, kname in ((api.KERNEL_LOCKSTEP, "lockstep"), (api.KERNEL_STATE_MACHINE, "state machine")):
-                sc.set_kernel(kind)
-                frames.append(("lbvh %s/%s" % (mname, kname), sc.render(desc.cam_pos, tr, desc.width, desc.height, desc.depth)))
+        for build, bname in ((api.BUILD_SAH, "sah"), (api.BUILD_FAST, "morton")):
+            sc.set_build(build)
+            sc.commit(0, api.ACCEL_LBVH)
+            hoisted = int(sc.hoisted(0).size)
+            for mode, mname in ((api.TRAVERSAL_PER_LANE, "per lane"), (api.TRAVERSAL_PACKET, "packets")):
+                sc.set_traversal(mode)
+                for kind, kname in ((api.KERNEL_LOCKSTEP, "lockstep"), (api.KERNEL_STATE_MACHINE, "state machine")):
+                    sc.set_kernel(kind)
+                    frames.append(("lbvh %s %s/%s" % (bname, mname, kname), sc.render(desc.cam_pos, tr, desc.width, desc.height, desc.depth)))
     return frames, hoisted
 
 

@@ -59,14 +59,39 @@ def _check_tree(nodes, tris, hoisted=()):
     return max_depth
 
 
-def test_tree_invariants():
+@pytest.mark.parametrize("build", [api.BUILD_FAST, api.BUILD_SAH])
+def test_tree_invariants(build):
     for desc in (scenes.stock(8, 8), scenes.spheres(3, 2, 8, 8), scenes.spheres(2, 3, 8, 8, seed=7)):
         with api.Scene.from_desc(desc) as sc:
+            sc.set_build(build)
             sc.commit(0, api.ACCEL_LBVH)
             assert sc.accel(0) == api.ACCEL_LBVH
             depth = _check_tree(sc.bvh(0), sc.triangles(), sc.hoisted(0))
-            assert depth <= 62
+            assert depth <= 62 and depth == sc.bvh_depth(0)[0]
             assert sc.build_ms(0) > 0
+
+
+def test_sah_tree_is_the_default_and_the_cheaper_one_to_cross():
+    """rt_scene_set_build: the SAH topology is what a commit builds unless told otherwise; on tessellated spheres its
+    sum of child-box areas (the expected number of box tests of a random ray, up to a constant) is below
+    the Morton/Karras tree's; changing the knob makes the committed tree stale."""
+    desc = scenes.spheres(6, 3, 8, 8)
+    cost = {}
+    with api.Scene.from_desc(desc) as sc:
+        sc.commit(0, api.ACCEL_LBVH)
+        default_nodes = sc.bvh(0).copy()
+        for build in (api.BUILD_SAH, api.BUILD_FAST):
+            sc.set_build(build)
+            sc.commit(0, api.ACCEL_LBVH)
+            nodes = sc.bvh(0)
+            _check_tree(nodes, sc.triangles(), sc.hoisted(0))
+            e = np.concatenate([nodes[:, 3:6] - nodes[:, 0:3], nodes[:, 9:12] - nodes[:, 6:9]]).astype(np.float64)
+            cost[build] = float((e[:, 0] * e[:, 1] + e[:, 1] * e[:, 2] + e[:, 2] * e[:, 0]).sum())
+            if build == api.BUILD_SAH:
+                assert np.array_equal(nodes.view(np.uint32), default_nodes.view(np.uint32))
+        assert cost[api.BUILD_SAH] < 0.95 * cost[api.BUILD_FAST], cost
+        with pytest.raises(api.RtError):
+            sc.set_build(7)
 
 
 def _box_area(tris):
@@ -272,8 +297,10 @@ def _rays_into_the_corner(tris, n_random, seed):
     return np.asarray(rays, np.float32)
 
 
-def test_deep_tree_within_the_per_lane_stack(oracle):
-    """A 4-wide tree ~19 levels deep: the per-lane walk keeps up to 3 entries per level, far past the 16
+@pytest.mark.parametrize("build", [api.BUILD_FAST, api.BUILD_SAH])
+def test_deep_tree_within_the_per_lane_stack(oracle, build):
+    """A 4-wide tree ~19 levels deep (Morton/Karras build; the SAH build of the same scene is whatever it
+    is, at most 63 binary levels): the per-lane walk keeps up to 3 entries per level, far past the 16
     entries it holds in LDS and close to the RT_STACK_LIMIT of 64.  Frames and ray batches by the
     per-lane walk, by packets and by brute force are the oracle's."""
     desc, tris = _graded_chain(54, 3)
@@ -283,14 +310,17 @@ def test_deep_tree_within_the_per_lane_stack(oracle):
     want = oracle.render_desc(desc, threads=4)
     assert (want.max(axis=2) > 0).sum() >= 20
     with api.Scene.from_desc(desc) as sc:
+        sc.set_build(build)
         sc.commit(0, api.ACCEL_LBVH)
         d2, d4 = sc.bvh_depth(0)
-        assert 40 <= d2 <= 63 and 16 < 3 * d4 <= api.STACK_LIMIT, (d2, d4)
+        if build == api.BUILD_FAST:
+            assert 40 <= d2 <= 63 and 16 < 3 * d4 <= api.STACK_LIMIT, (d2, d4)
+        assert 1 <= d2 <= 63, (d2, d4)
         assert _check_tree(sc.bvh(0), sc.triangles(), sc.hoisted(0)) == d2
         tr = api.camera_trans(desc.cam_rot)
         for mode in (api.TRAVERSAL_PER_LANE, api.TRAVERSAL_PACKET):
             sc.set_traversal(mode)
-            assert sc.traversal(0, tr, desc.width, desc.height) == mode
+            assert sc.traversal(0, tr, desc.width, desc.height) == (mode if 3 * d4 <= api.STACK_LIMIT else api.TRAVERSAL_PACKET)
             got = sc.render(desc.cam_pos, tr, desc.width, desc.height, desc.depth)
             assert np.array_equal(_bits(got), _bits(want)), mode
             out = sc.cast_rays(rays)
@@ -310,6 +340,7 @@ def test_tree_too_deep_for_the_per_lane_stack_goes_by_packets(oracle):
     want_rays = np.stack([oracle.cast_ray(otris, r[0:3], r[3:6], int(r[6])) for r in rays])
     want = oracle.render_desc(desc, threads=4)
     with api.Scene.from_desc(desc) as sc:
+        sc.set_build(api.BUILD_FAST)             # (the Morton/Karras tree of this scene is the deep one)
         sc.commit(0, api.ACCEL_LBVH)
         d2, d4 = sc.bvh_depth(0)
         assert d2 <= 63 and 3 * d4 > api.STACK_LIMIT, (d2, d4)
