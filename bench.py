@@ -75,6 +75,8 @@ def parse():
     ap.add_argument("--traversal", default="auto", choices=["auto", "per-lane", "packet"])
     ap.add_argument("--kernel", default="auto", choices=["auto", "state-machine", "lockstep"], help="form of the brute-force render kernel (rt_scene_set_kernel)")
     ap.add_argument("--build", default="sah", choices=["fast", "sah"], help="how LBVH commits build their tree (rt_scene_set_build)")
+    ap.add_argument("--exchange", default="rgba8", choices=["rgba8", "f32"],
+                    help="pixel format of the frames the row-tile mode renders and gathers (RT_OUT_RGBA8 or binary32 RGB)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo lets several ranks share one GPU to rehearse the N>1 path")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -280,24 +282,27 @@ def hand_off(api, torch, w):
     for i in range(n):
         sc.render(w.cams[i % N_POSES], w.trans[i % N_POSES], W, H, D)
     sync_ms = (time.perf_counter() - t0) / n * 1e3
-    bufs = [api.HostFrame(W, H), api.HostFrame(W, H)]
-    tickets = [sc.render_async(w.cams[0], w.trans[0], W, H, D, bufs[0]), None]
-    sc.render_wait(tickets[0])
-    t0 = time.perf_counter()
-    for i in range(n):
-        tickets[i & 1] = sc.render_async(w.cams[i % N_POSES], w.trans[i % N_POSES], W, H, D, bufs[i & 1])
-        if i > 0:
-            sc.render_wait(tickets[(i - 1) & 1])
-    sc.render_wait(tickets[(n - 1) & 1])
-    async_ms = (time.perf_counter() - t0) / n * 1e3
-    for b in bufs:
-        b.close()
+    async_ms = {}
+    for rgba8 in (False, True):
+        bufs = [api.HostFrame(W, H, rgba8=rgba8), api.HostFrame(W, H, rgba8=rgba8)]
+        tickets = [sc.render_async(w.cams[0], w.trans[0], W, H, D, bufs[0]), None]
+        sc.render_wait(tickets[0])
+        t0 = time.perf_counter()
+        for i in range(n):
+            tickets[i & 1] = sc.render_async(w.cams[i % N_POSES], w.trans[i % N_POSES], W, H, D, bufs[i & 1])
+            if i > 0:
+                sc.render_wait(tickets[(i - 1) & 1])
+        sc.render_wait(tickets[(n - 1) & 1])
+        async_ms[rgba8] = (time.perf_counter() - t0) / n * 1e3
+        for b in bufs:
+            b.close()
     mb = H * W * 12 / 1e6
-    return {"single_frame_launch_us": single_us, "end_to_end_ms": sync_ms, "end_to_end_async_ms": async_ms,
-            "frame_MB": mb, "async_GBps": mb / async_ms,
+    return {"single_frame_launch_us": single_us, "end_to_end_ms": sync_ms, "end_to_end_async_ms": async_ms[False],
+            "frame_MB": mb, "async_GBps": mb / async_ms[False],
+            "end_to_end_async_rgba8_ms": async_ms[True], "frame_rgba8_MB": mb / 3,
             "note": "one %dx%d frame per launch (HIP events, %d back-to-back launches); end_to_end_ms = rt_render incl. the D2H copy into "
                     "pageable memory; end_to_end_async_ms = rt_render_async into two pinned frames, frame f copying while f+1 renders "
-                    "(wall per frame)" % (W, H, n)}
+                    "(wall per frame); end_to_end_async_rgba8_ms = the same with RT_OUT_RGBA8 frames (the 8-bit pixels the viewer displays)" % (W, H, n)}
 
 
 def read_profile_json(name):
@@ -369,7 +374,7 @@ def run_frames_mode(args, api, torch, dist, rank, world, dev, on_gpu, name):
     if rank == 0 and world == 1:
         if not args.no_configs:
             out["configs"] = [side_config(api, torch, n, dev, args) for n in
-                              ("stock800", "mirrors4k", "spheres800", "spheres4k", "sweep8k") if n != name]
+                              ("stock800", "mirrors4k", "spheres800", "spheres4k", "sweep8k", "sweep8k_spheres") if n != name]
         if not args.no_cpu:
             cb = cpu_baseline(w_desc, args.cpu_seconds)
             out["cpu_baseline"] = cb
@@ -384,7 +389,9 @@ def run_frames_mode(args, api, torch, dist, rank, world, dev, on_gpu, name):
 
 def run_tile_mode(args, api, torch, dist, rank, world, dev, on_gpu, name):
     """BASELINE config 5: every rank renders its interleaved 16-row tiles of the SAME frame, one exchange
-    step per frame gathers them on rank 0 (pipelined: frame f+1 renders while f is in flight)."""
+    step per frame gathers them on rank 0 (pipelined: frame f+1 renders while f is in flight).  The frames
+    travel as packed 8-bit pixels (RT_OUT_RGBA8: what the reference's viewer displays, a third of the bytes,
+    SURVEY 8e) unless --exchange f32; the other format is measured on a few frames as a secondary figure."""
     from raytracing_amd import sharding
     w = Workload(api, torch, name, dev, args, frames_per_launch=1)
     W, H, D, sc = w.W, w.H, w.D, w.scene
@@ -392,26 +399,69 @@ def run_tile_mode(args, api, torch, dist, rank, world, dev, on_gpu, name):
     w.count(frames)
     tile_rows = 16
     rows = api.shard_rows(H, tile_rows, rank, world)
-    ex = sharding.TileExchange(dist, rank, world, H, W, tile_rows,
-                               lambda n: torch.empty(n, dtype=torch.float32, device="cuda" if on_gpu else "cpu"), depth=2)
-    stage = None if on_gpu else torch.empty(rows * W * 3, dtype=torch.float32, device="cuda")   # gloo rehearsal: shards go through host memory
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in frames]
+    where = "cuda" if on_gpu else "cpu"
 
-    def run(fs, timed):
-        done = []
-        for i, f in enumerate(fs):
-            buf = ex.shard(i)
-            dst = buf if on_gpu else stage
-            if timed:
-                evs[i][0].record()
-            sc.render_tiles_device(dev, w.cams[f], w.trans[f], W, H, D, api.STRICT, tile_rows, rank, world, dst.data_ptr(), w.stream)
-            if timed:
-                evs[i][1].record()
-            if not on_gpu:
-                buf.copy_(stage)
-            done += ex.submit(i)
-        done += ex.drain()
-        return done
+    def leg(fmt, frames, warmup, check):
+        """Timed exchange of `frames` in format `fmt` -> (wall s, this rank's mean kernel ms, gather check or None)."""
+        rgba8 = fmt == "rgba8"
+        ch, dtype, mode = (1, torch.int32, api.STRICT | api.OUT_RGBA8) if rgba8 else (3, torch.float32, api.STRICT)
+        ex = sharding.TileExchange(dist, rank, world, H, W, tile_rows, lambda n: torch.empty(n, dtype=dtype, device=where), depth=2, channels=ch)
+        stage = None if on_gpu else torch.empty(rows * W * ch, dtype=dtype, device="cuda")   # gloo rehearsal: shards go through host memory
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in frames]
+
+        def run(fs, timed):
+            done = []
+            for i, f in enumerate(fs):
+                buf = ex.shard(i)
+                dst = buf if on_gpu else stage
+                if timed:
+                    evs[i][0].record()
+                sc.render_tiles_device(dev, w.cams[f], w.trans[f], W, H, D, mode, tile_rows, rank, world, dst.data_ptr(), w.stream)
+                if timed:
+                    evs[i][1].record()
+                if not on_gpu:
+                    buf.copy_(stage)
+                done += ex.submit(i)
+            done += ex.drain()
+            return done
+
+        run([frames[s % len(frames)] for s in range(warmup)], False)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(frames, True)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)      # this rank's shard kernel, HIP events on the launch stream
+        verdict = None
+        if check:
+            # outside the timed region: one more frame through the same exchange, compared on rank 0 with the frame
+            # one GPU renders in one piece — the gathered framebuffer must be that frame, bit for bit
+            got = run([frames[-1]], False)
+            if rank == 0:
+                whole = torch.empty(H * W * ch, dtype=dtype, device="cuda")
+                sc.render_device(dev, w.cams[frames[-1]], w.trans[frames[-1]], W, H, D, mode, whole.data_ptr(), w.stream)
+                torch.cuda.synchronize()
+                same = torch.equal(got[-1][1].to("cuda").view(torch.int32), whole.view(torch.int32))
+                verdict = "bit-identical to the single-GPU frame" if same else "DIFFERS from the single-GPU frame"
+                if rgba8 and same:
+                    # and the 8-bit frame is the GL unorm conversion of the binary32 frame (SURVEY 8a)
+                    f32 = torch.empty(H * W * 3, dtype=torch.float32, device="cuda")
+                    sc.render_device(dev, w.cams[frames[-1]], w.trans[frames[-1]], W, H, D, api.STRICT, f32.data_ptr(), w.stream)
+                    torch.cuda.synchronize()
+                    c = torch.where(f32 > 0, f32, torch.zeros_like(f32)).clamp_(max=1.0)
+                    q = (c * 255.0 + 0.5).to(torch.int32).view(H * W, 3)
+                    want = q[:, 0] | (q[:, 1] << 8) | (q[:, 2] << 16) | torch.tensor(-16777216, dtype=torch.int32, device="cuda")
+                    verdict += "; = unorm8 of the binary32 frame" if torch.equal(want, whole) else "; DIFFERS from unorm8 of the binary32 frame"
+                    del f32
+                del whole
+        t = torch.tensor([wall, kernel_ms], dtype=torch.float64, device=where)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        del ex
+        return float(t[0].item()), kernel_ms, float(t[1].item()), verdict
 
     # the same frames by ONE GPU in one piece (rank 0, outside the timed region): the N=1 point of this workload
     single = None
@@ -426,35 +476,14 @@ def run_tile_mode(args, api, torch, dist, rank, world, dev, on_gpu, name):
             torch.cuda.synchronize()
             t1 = time.perf_counter() - t0
         single = {"ms_per_frame": t1 / k * 1e3, "value": sum(w.rays_of[f] for f in frames[:k]) / t1 / 1e6, "frames": k,
-                  "note": "whole frames on rank 0's GPU alone, one frame per launch, frames resident in HBM, no exchange"}
+                  "note": "whole binary32 frames on rank 0's GPU alone, one frame per launch, frames resident in HBM, no exchange"}
         del whole
-    run([frames[s % len(frames)] for s in range(args.warmup)], False)
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(frames, True)
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    # outside the timed region: one more frame through the same exchange, compared on rank 0 with the frame
-    # one GPU renders in one piece — the gathered framebuffer must be the reference's `data`, bit for bit
-    check = None
-    got = run([frames[-1]], False)
-    if rank == 0:
-        whole = torch.empty(H * W * 3, dtype=torch.float32, device="cuda")
-        sc.render_device(dev, w.cams[frames[-1]], w.trans[frames[-1]], W, H, D, api.STRICT, whole.data_ptr(), w.stream)
-        torch.cuda.synchronize()
-        full = got[-1][1]
-        same = torch.equal(full.to("cuda").view(torch.int32), whole.view(torch.int32))
-        check = "bit-identical to the single-GPU frame" if same else "DIFFERS from the single-GPU frame"
-        del whole
-    kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)          # this rank's shard kernel, HIP events on the launch stream
-    where = "cuda" if on_gpu else "cpu"
-    t = torch.tensor([wall, kernel_ms], dtype=torch.float64, device=where)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall, kernel_ms_max = float(t[0].item()), float(t[1].item())
+    fmt = args.exchange
+    other = "f32" if fmt == "rgba8" else "rgba8"
+    wall, kernel_ms, kernel_ms_max, check = leg(fmt, frames, args.warmup, True)
+    k2 = min(8, len(frames))
+    wall2, _, kmax2, _ = leg(other, frames[:k2], min(2, args.warmup), False)
+    bytes_px = {"f32": 12, "rgba8": 4}
     out = None
     if rank == 0:
         rays = float(sum(w.rays_of[f] for f in frames))
@@ -466,17 +495,22 @@ def run_tile_mode(args, api, torch, dist, rank, world, dev, on_gpu, name):
             "ms_per_frame": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": w.label + ", interleaved 16-row tiles + gather to rank 0", "accel": w.accel_name, "traversal": w.traversal(),
-                       "width": W, "height": H, "max_bounces": D, "triangles": sc.n_triangles, "lights": sc.n_lights,
+                       "build": w.build, "width": W, "height": H, "max_bounces": D, "triangles": sc.n_triangles, "lights": sc.n_lights,
                        "frames": "64-pose camera path (rt_camera_path), step s = pose s mod 64, every rank renders its tiles of it",
                        "rays_per_frame_mean": rays / args.steps, "parallelism": "row tiles x%d" % world,
-                       "exchange": "point-to-point sends of the compact fp32 shards to rank 0 (%s), two shard buffers per rank" % args.backend},
+                       "output": ("packed 8-bit RGBA pixels (RT_OUT_RGBA8: the GL unorm conversion of the binary32 colour, what the reference's viewer displays)"
+                                  if fmt == "rgba8" else "binary32 RGB (the reference's `data`)"),
+                       "exchange": "point-to-point sends of the compact %s shards to rank 0 (%s), two shard buffers per rank" % (fmt, args.backend)},
             "roofline": roofline_of(flops / args.steps * share, kernel_ms, 1, args.steps, name),
-            "exchange": {"kernel_ms_rank0": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
+            "exchange": {"format": fmt, "kernel_ms_rank0": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
                          "non_render_ms_per_frame": wall / args.steps * 1e3 - kernel_ms_max,
-                         "shard_MB": rows * W * 12 / 1e6,
+                         "shard_MB": rows * W * bytes_px[fmt] / 1e6,
                          "note": "roofline is rank 0's shard kernel: the frame's counted FLOPs x its share of the rows (%d of %d, interleaved "
                                  "tiles); non_render_ms_per_frame = wall per frame minus the slowest rank's kernel = exchange + "
                                  "de-interleave not hidden behind rendering" % (rows, H)},
+            "exchange_other_format": {"format": other, "frames": k2, "ms_per_frame": wall2 / k2 * 1e3,
+                                      "value": float(sum(w.rays_of[f] for f in frames[:k2])) / wall2 / 1e6,
+                                      "kernel_ms_max_over_ranks": kmax2, "shard_MB": rows * W * bytes_px[other] / 1e6},
             "single_gpu": single,
             "gather_check": check,
         }

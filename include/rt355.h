@@ -45,6 +45,15 @@ extern "C" {
  * the reference's diagonal seams by a pixel; it was dropped)  Any other value is
  * RT_ERR_INVALID. */
 #define RT_RENDER_STRICT 0
+/* Output format bit, OR-ed into render_flags of rt_render, rt_render_device, rt_render_frames_device,
+ * rt_render_tiles_device and rt_render_async (RT_ERR_INVALID elsewhere): the output buffer takes ONE packed
+ * 8-bit pixel per 4 bytes (R, G, B, 255 in memory order) instead of three floats — the pixel the
+ * reference's viewer ends up displaying, i.e. the GL unorm conversion glTexImage2D applies to `data`
+ * (Src:1270): q = (int)(c * 255.0f + 0.5f), NaN and negative -> 0.  The arithmetic up to the stored
+ * colour is the same; a frame is a third of the bytes to copy to the host or to gather from other GPUs
+ * (8K: 133 MB instead of 398 MB).  The `float*` output arguments then point at width*height 4-byte
+ * pixels, and frame_stride_floats counts 4-byte pixels. */
+#define RT_OUT_RGBA8 0x100
 
 /* One triangle record as the reference stores it (Src:31-43), 28 floats:
  * p[3] n[3] p1[3] p2[3] p3[3] edge0[3] edge1[3] edge2[3] color[3] shininess */

@@ -25,6 +25,7 @@ TRAVERSAL_AUTO, TRAVERSAL_PER_LANE, TRAVERSAL_PACKET = 0, 1, 2
 KERNEL_AUTO, KERNEL_STATE_MACHINE, KERNEL_LOCKSTEP = 0, 1, 2
 BUILD_FAST, BUILD_SAH = 0, 1
 STRICT = 0            # RT_RENDER_STRICT: the only render mode (bit-identical frames)
+OUT_RGBA8 = 0x100     # RT_OUT_RGBA8: the output buffer takes packed 8-bit pixels instead of three floats
 STACK_LIMIT = 64      # RT_STACK_LIMIT
 NOALLOC_MAX_RAYS = 16384
 TRI_FLOATS = 28
@@ -138,7 +139,7 @@ def lib():
     L.rt_camera_frame_time.argtypes = [cp, cf]
     L.rt_camera_step.argtypes = [cp, C.c_uint, cf]
     L.rt_camera_path.argtypes = [cp, ci, C.POINTER(C.c_uint), _fp, _fp, _fp]
-    L.rt_render.argtypes = [vp, _fp, _fp, ci, ci, ci, ci, _fp]
+    L.rt_render.argtypes = [vp, _fp, _fp, ci, ci, ci, ci, vp]
     L.rt_render_device.argtypes = [vp, ci, _fp, _fp, ci, ci, ci, ci, vp, vp]
     L.rt_render_tiles_device.argtypes = [vp, ci, _fp, _fp, ci, ci, ci, ci, ci, ci, ci, vp, vp]
     L.rt_render_frames_device.argtypes = [vp, ci, ci, _fp, _fp, ci, ci, ci, ci, vp, C.c_size_t, vp]
@@ -186,14 +187,19 @@ def _p(a: np.ndarray):
 
 class HostFrame:
     """A pinned host framebuffer (rt_frame_alloc: what replaces `data = malloc(...)`, Source.cpp:1035)
-    as an (H, W, 3) float32 array; rt_render_async copies into it at PCIe speed."""
+    as an (H, W, 3) float32 array — or, rgba8=True, an (H, W, 4) uint8 array for OUT_RGBA8 frames;
+    rt_render_async copies into it at PCIe speed."""
 
-    def __init__(self, width: int, height: int):
-        n = int(width) * int(height) * 3
+    def __init__(self, width: int, height: int, rgba8: bool = False):
+        n = int(width) * int(height) * (1 if rgba8 else 3)
         self._p = lib().rt_frame_alloc(n)
         if not self._p:
             raise RtError(-4, lib().rt_last_error().decode())
-        self.array = np.ctypeslib.as_array(C.cast(self._p, _fp), shape=(n,)).reshape(int(height), int(width), 3)
+        self.rgba8 = bool(rgba8)
+        if rgba8:
+            self.array = np.ctypeslib.as_array(C.cast(self._p, C.POINTER(C.c_uint8)), shape=(n * 4,)).reshape(int(height), int(width), 4)
+        else:
+            self.array = np.ctypeslib.as_array(C.cast(self._p, _fp), shape=(n,)).reshape(int(height), int(width), 3)
 
     @property
     def ptr(self) -> int:
@@ -455,17 +461,20 @@ class Scene:
     # -- render: replaces the getPixelData loop -------------------------------------------------
     def render(self, cam_pos, trans16, width: int, height: int, max_bounces: int = 1,
                mode: int = STRICT) -> np.ndarray:
-        """(H, W, 3) float32, data[(y*w+x)*3+c], row 0 = bottom — Source.cpp:550, 612-614."""
+        """(H, W, 3) float32, data[(y*w+x)*3+c], row 0 = bottom — Source.cpp:550, 612-614; with
+        mode | OUT_RGBA8 the (H, W, 4) uint8 frame the reference's viewer displays (GL unorm, alpha 255)."""
         cam, tr = _f32(cam_pos), _f32(trans16)
-        out = np.empty((height, width, 3), dtype=np.float32)
-        _check(lib().rt_render(self._h, _p(cam), _p(tr), width, height, max_bounces, mode, _p(out)))
+        out = np.empty((height, width, 4), dtype=np.uint8) if mode & OUT_RGBA8 else np.empty((height, width, 3), dtype=np.float32)
+        _check(lib().rt_render(self._h, _p(cam), _p(tr), width, height, max_bounces, mode, C.c_void_p(out.ctypes.data)))
         return out
 
     def render_async(self, cam_pos, trans16, width: int, height: int, max_bounces: int, out: "HostFrame") -> int:
-        """rt_render_async into a pinned HostFrame (or any float32 array of the frame's size) -> ticket."""
+        """rt_render_async into a pinned HostFrame (or any array of the frame's size: float32 RGB, or uint8 RGBA
+        for an OUT_RGBA8 frame) -> ticket."""
         cam, tr = _f32(cam_pos), _f32(trans16)
         ptr = out.ptr if isinstance(out, HostFrame) else out.ctypes.data
-        return _check(lib().rt_render_async(self._h, _p(cam), _p(tr), width, height, max_bounces, STRICT, C.c_void_p(ptr)))
+        rgba8 = out.rgba8 if isinstance(out, HostFrame) else out.dtype == np.uint8
+        return _check(lib().rt_render_async(self._h, _p(cam), _p(tr), width, height, max_bounces, STRICT | (OUT_RGBA8 if rgba8 else 0), C.c_void_p(ptr)))
 
     def render_wait(self, ticket: int) -> None:
         _check(lib().rt_render_wait(self._h, int(ticket)))
@@ -497,7 +506,7 @@ class Scene:
         cam, tr = _f32(cam_pos3).reshape(-1, 3), _f32(trans16).reshape(-1, 16)
         if cam.shape[0] != tr.shape[0]:
             raise ValueError("cam_pos3 and trans16 disagree on the frame count")
-        stride = frame_stride_floats or width * height * 3
+        stride = frame_stride_floats or width * height * (1 if mode & OUT_RGBA8 else 3)
         _check(lib().rt_render_frames_device(self._h, device, cam.shape[0], _p(cam), _p(tr), width, height,
                                              max_bounces, mode, C.c_void_p(d_out_ptr), stride, C.c_void_p(stream)))
 

@@ -96,7 +96,8 @@ int check_frame_args(const char* fn, const rt_scene* s, const float* cam, const 
 	return RT_OK;
 }
 
-int check_flags(const char* fn, int render_flags) {
+int check_flags(const char* fn, int render_flags, bool rgba8_ok = false) {
+	if (rgba8_ok) render_flags &= ~RT_OUT_RGBA8;
 	if (render_flags != RT_RENDER_STRICT) { set_error("%s: unknown render flag %d (RT_RENDER_STRICT is the only mode)", fn, render_flags); return RT_ERR_INVALID; }
 	return RT_OK;
 }
@@ -149,6 +150,7 @@ void fill_frame(rt_scene* s, FrameParams& fp, const float cam[3], const float tr
 	fp.local_rows = h;
 	fp.tiles_per_wave = 0;
 	fp.out = nullptr;
+	fp.rgba8 = 0;
 	fp.counters = nullptr;
 }
 
@@ -392,7 +394,7 @@ int rt_render_tiles_device(rt_scene* s, int device, const float cam_pos[3], cons
 	if (rc != RT_OK) return rc;
 	if (!d_out_compact) { set_error("rt_render_tiles_device: NULL output"); return RT_ERR_INVALID; }
 	if (tile_rows <= 0 || tile_first < 0 || tile_stride <= 0) { set_error("rt_render_tiles_device: bad tile parameters"); return RT_ERR_INVALID; }
-	if ((rc = check_flags("rt_render_tiles_device", render_flags)) != RT_OK) return rc;
+	if ((rc = check_flags("rt_render_tiles_device", render_flags, true)) != RT_OK) return rc;
 	DeviceGuard g(device);
 	if (!g.ok) return g.rc;
 	DeviceState* d = committed("rt_render_tiles_device", s, device);
@@ -405,7 +407,8 @@ int rt_render_tiles_device(rt_scene* s, int device, const float cam_pos[3], cons
 	fp.local_rows = rt_shard_rows(height, tile_rows, tile_first, tile_stride);
 	fp.tiles_per_wave = s->tiles_per_wave;
 	fp.out = d_out_compact;
-	return launch_render(dev_scene(s, *d), fp, d->accel, render_flags, false, (hipStream_t)hip_stream);
+	fp.rgba8 = (render_flags & RT_OUT_RGBA8) ? 1 : 0;
+	return launch_render(dev_scene(s, *d), fp, d->accel, RT_RENDER_STRICT, false, (hipStream_t)hip_stream);
 }
 
 int rt_render_frames_device(rt_scene* s, int device, int n_frames, const float* cam_pos3, const float* trans16,
@@ -416,8 +419,9 @@ int rt_render_frames_device(rt_scene* s, int device, int n_frames, const float* 
 	int rc = check_frame_args("rt_render_frames_device", s, cam_pos3, trans16, width, height, max_bounces);
 	if (rc != RT_OK) return rc;
 	if (!d_out_rgb) { set_error("rt_render_frames_device: NULL output"); return RT_ERR_INVALID; }
-	if (frame_stride_floats < (size_t)width * height * 3) { set_error("rt_render_frames_device: frame stride smaller than a frame"); return RT_ERR_INVALID; }
-	if ((rc = check_flags("rt_render_frames_device", render_flags)) != RT_OK) return rc;
+	if ((rc = check_flags("rt_render_frames_device", render_flags, true)) != RT_OK) return rc;
+	const bool rgba8 = (render_flags & RT_OUT_RGBA8) != 0;
+	if (frame_stride_floats < (size_t)width * height * (rgba8 ? 1 : 3)) { set_error("rt_render_frames_device: frame stride smaller than a frame"); return RT_ERR_INVALID; }
 	DeviceGuard g(device);
 	if (!g.ok) return g.rc;
 	DeviceState* d = committed("rt_render_frames_device", s, device);
@@ -434,7 +438,8 @@ int rt_render_frames_device(rt_scene* s, int device, int n_frames, const float* 
 		fp.frame_stride = (long long)frame_stride_floats;
 		fp.tiles_per_wave = s->tiles_per_wave;
 		fp.out = d_out_rgb + (size_t)f0 * frame_stride_floats;
-		rc = launch_render(sc, fp, d->accel, render_flags, false, (hipStream_t)hip_stream);
+		fp.rgba8 = rgba8 ? 1 : 0;
+		rc = launch_render(sc, fp, d->accel, RT_RENDER_STRICT, false, (hipStream_t)hip_stream);
 		if (rc != RT_OK) return rc;
 	}
 	return RT_OK;
@@ -470,7 +475,7 @@ int rt_render(rt_scene* s, const float cam_pos[3], const float trans16[16], int 
 	if (!g.ok) return g.rc;
 	DeviceState* d = committed("rt_render", s, device);
 	if (!d) return RT_ERR_STATE;
-	const size_t bytes = (size_t)width * height * 3 * sizeof(float);
+	const size_t bytes = (size_t)width * height * ((render_flags & RT_OUT_RGBA8) ? 1 : 3) * sizeof(float);
 	rc = ensure_frame(*d, bytes);
 	if (rc != RT_OK) return rc;
 	rc = rt_render_device(s, device, cam_pos, trans16, width, height, max_bounces, render_flags, (float*)d->frame, nullptr);
@@ -526,6 +531,7 @@ int rt_render_multi(rt_scene* s, const int* devices, int n_devices, const float 
 	int rc = check_frame_args("rt_render_multi", s, cam_pos, trans16, width, height, max_bounces);
 	if (rc != RT_OK) return rc;
 	if (!devices || n_devices <= 0 || !out_rgb || tile_rows <= 0) { set_error("rt_render_multi: bad argument"); return RT_ERR_INVALID; }
+	if ((rc = check_flags("rt_render_multi", render_flags)) != RT_OK) return rc;
 	for (int a = 0; a < n_devices; a++)
 		for (int b = a + 1; b < n_devices; b++)
 			if (devices[a] == devices[b]) { set_error("rt_render_multi: device %d listed twice", devices[a]); return RT_ERR_INVALID; }
@@ -639,7 +645,7 @@ int rt_render_async(rt_scene* s, const float cam_pos[3], const float trans16[16]
 	int rc = check_frame_args("rt_render_async", s, cam_pos, trans16, width, height, max_bounces);
 	if (rc != RT_OK) return rc;
 	if (!out_rgb) { set_error("rt_render_async: NULL output"); return RT_ERR_INVALID; }
-	if ((rc = check_flags("rt_render_async", render_flags)) != RT_OK) return rc;
+	if ((rc = check_flags("rt_render_async", render_flags, true)) != RT_OK) return rc;
 	if (s->first_device < 0) { set_error("rt_render_async: scene is not committed to any device"); return RT_ERR_STATE; }
 	const int device = s->first_device;
 	DeviceGuard g(device);
@@ -657,7 +663,7 @@ int rt_render_async(rt_scene* s, const float cam_pos[3], const float trans16[16]
 	}
 	const long long ticket = s->next_ticket;
 	const int slot = (int)(ticket & 1);
-	const size_t bytes = (size_t)width * height * 3 * sizeof(float);
+	const size_t bytes = (size_t)width * height * ((render_flags & RT_OUT_RGBA8) ? 1 : 3) * sizeof(float);
 	if (d->ticket_of_slot[slot] >= 0) {
 		// the device frame of this slot is free once its copy (two frames ago) has finished
 		if (d->aframe_bytes[slot] < bytes) RT_HIP(hipEventSynchronize(d->copied[slot]));   // about to be reallocated

@@ -103,7 +103,7 @@ struct FrameParams {
 	// each XCD's L2 then sees the part of the scene behind one band at a time, and the rotation with
 	// the frame number evens out bands of different cost over the frames of the launch.
 	unsigned int band_blocks;
-	long long frame_stride;         // floats between consecutive frames in `out`
+	long long frame_stride;         // 4-byte elements between consecutive frames in `out`
 	int width, height;      // Source.cpp:887-888
 	int max_bounces;        // Source.cpp:567
 	int tile_rows, tile_first, tile_stride;
@@ -115,7 +115,8 @@ struct FrameParams {
 	// host against the IEEE division and sets uv_fast only when all of them agree bit for bit.
 	float rcp_w, rcp_h;
 	int uv_fast;
-	float* out;             // local_rows * width * 3 floats
+	float* out;             // local_rows * width * 3 floats, or (rgba8) local_rows * width packed 8-bit pixels
+	int rgba8;              // RT_OUT_RGBA8: store_pixel (rt_kernels.hip)
 	unsigned long long* counters;   // rt_stats as 10 x u64, or null
 };
 

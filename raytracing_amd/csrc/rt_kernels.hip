@@ -492,6 +492,24 @@ __device__ __forceinline__ float div65025(float x) {
 #endif
 }
 
+// One pixel into the frame: three binary32 channels (Source.cpp:612-614), or — FrameParams::rgba8 — the 8-bit pixel
+// the reference's viewer ends up displaying: the GL unorm conversion of glTexImage2D(GL_RGB, GL_FLOAT) (Source.cpp:1270)
+// as SURVEY 8a fixes it, q = (int)(c * 255.0f + 0.5f), NaN and negative -> 0, packed R, G, B, 255 in memory order.
+__device__ __forceinline__ unsigned int unorm8(float c) {
+	c = c > 0.0f ? c : 0.0f;                                  // (NaN fails the comparison)
+	c = c > 1.0f ? 1.0f : c;
+	return (unsigned int)(c * 255.0f + 0.5f);
+}
+__device__ __forceinline__ void store_pixel(const FrameParams& fp, int frame, long long pixel, vec3 c) {
+	if (fp.rgba8) {
+		unsigned int* out = (unsigned int*)fp.out + (long long)frame * fp.frame_stride + pixel;
+		*out = unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16) | 0xff000000u;
+	} else {
+		float* out = fp.out + (long long)frame * fp.frame_stride + pixel * 3;   // Source.cpp:550
+		out[0] = c.x; out[1] = c.y; out[2] = c.z;                               // Source.cpp:612-614
+	}
+}
+
 // ---- pixel <-> work index ------------------------------------------------------------------
 // Work items are numbered tile-major: item g -> tile g/64 (tiles run left to right, then up),
 // pixel g%64 inside the 8x8 tile.  A wave owns `tiles_per_wave` consecutive tiles.
@@ -835,7 +853,7 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 					const PixelId px = pixel_of(g, base_tile, tx0, ty0, tiles_x, fp.width, fp.local_rows);
 					if (px.inside) {
 						const int y = global_row(px.ly, fp);
-						out_index = (px.ly * fp.width + px.x) * 3;            // Source.cpp:550 (local rows)
+						out_index = px.ly * fp.width + px.x;                  // pixel of the shard's local rows (Source.cpp:550)
 						d = primary_dir(px.x, y, fp, frame);
 						o = cam;                                             // Source.cpp:545
 						skip = -1;
@@ -954,8 +972,7 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 			if (c.x > 1.0f) c.x = 1.0f;                                      // Source.cpp:602-610
 			if (c.y > 1.0f) c.y = 1.0f;
 			if (c.z > 1.0f) c.z = 1.0f;
-			float* out = fp.out + (long long)frame * fp.frame_stride + out_index;
-			out[0] = c.x; out[1] = c.y; out[2] = c.z;                        // Source.cpp:612-614
+			store_pixel(fp, frame, out_index, c);
 			stage = ST_IDLE;
 			lit_any = false;
 		}
@@ -1102,8 +1119,7 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 			if (c.x > 1.0f) c.x = 1.0f;                                      // Source.cpp:602-610
 			if (c.y > 1.0f) c.y = 1.0f;
 			if (c.z > 1.0f) c.z = 1.0f;
-			float* out = fp.out + (long long)frame * fp.frame_stride + (ly * fp.width + x) * 3;   // Source.cpp:550 (local rows)
-			out[0] = c.x; out[1] = c.y; out[2] = c.z;                        // Source.cpp:612-614
+			store_pixel(fp, frame, (long long)ly * fp.width + x, c);        // (local rows)
 		}
 	}
 #ifdef RT_PROFILE

@@ -38,16 +38,18 @@ def shard_rows(height: int, tile_rows: int, rank: int, world: int) -> int:
     return sum(r1 - r0 for r0, r1 in shard_tiles(height, tile_rows, rank, world))
 
 
-def scatter_shard_into_frame(full, shard, height: int, width: int, tile_rows: int, rank: int, world: int) -> None:
-    """De-interleave one compact shard (rows*width*3) into the full frame (height*width*3).
-    Works on torch tensors (CPU or GPU) and numpy arrays alike."""
-    fv = full.reshape(height, width * 3)
+def scatter_shard_into_frame(full, shard, height: int, width: int, tile_rows: int, rank: int, world: int,
+                             channels: int = 3) -> None:
+    """De-interleave one compact shard (rows*width*channels) into the full frame (height*width*channels).
+    channels: elements per pixel — 3 for float32 RGB frames, 1 for OUT_RGBA8 frames held as one 32-bit
+    element per pixel.  Works on torch tensors (CPU or GPU) and numpy arrays alike."""
+    fv = full.reshape(height, width * channels)
     rows = shard_rows(height, tile_rows, rank, world)
-    sv = shard.reshape(rows, width * 3)
+    sv = shard.reshape(rows, width * channels)
     n_full = height // (tile_rows * world)          # tile groups in which every rank has a whole tile
     if n_full > 0:
-        body = fv[: n_full * tile_rows * world].reshape(n_full, world, tile_rows, width * 3)
-        body[:, rank] = sv[: n_full * tile_rows].reshape(n_full, tile_rows, width * 3)
+        body = fv[: n_full * tile_rows * world].reshape(n_full, world, tile_rows, width * channels)
+        body[:, rank] = sv[: n_full * tile_rows].reshape(n_full, tile_rows, width * channels)
     r = n_full * tile_rows
     for r0, r1 in shard_tiles(height, tile_rows, rank, world)[n_full:]:
         fv[r0:r1] = sv[r: r + (r1 - r0)]
@@ -55,12 +57,12 @@ def scatter_shard_into_frame(full, shard, height: int, width: int, tile_rows: in
 
 
 def gather_frame(dist, shard, full, rank: int, world: int, height: int, width: int, tile_rows: int,
-                 recv_bufs: Optional[list] = None):
+                 recv_bufs: Optional[list] = None, channels: int = 3):
     """The exchange step: every rank's compact shard goes to rank 0 (point-to-point sends — on the
     GPU box 7 concurrent xGMI transfers into GPU 0), which scatters them into `full`.  Returns
     `full` on rank 0, None elsewhere.  `recv_bufs` lets the caller reuse receive buffers."""
     if world == 1:
-        scatter_shard_into_frame(full, shard, height, width, tile_rows, 0, 1)
+        scatter_shard_into_frame(full, shard, height, width, tile_rows, 0, 1, channels)
         return full
     if rank != 0:
         dist.send(shard, dst=0)
@@ -69,13 +71,13 @@ def gather_frame(dist, shard, full, rank: int, world: int, height: int, width: i
     reqs = []
     for k in range(1, world):
         if bufs[k] is None:
-            bufs[k] = shard.new_empty(shard_rows(height, tile_rows, k, world) * width * 3)
+            bufs[k] = shard.new_empty(shard_rows(height, tile_rows, k, world) * width * channels)
         reqs.append(dist.irecv(bufs[k], src=k))
-    scatter_shard_into_frame(full, shard, height, width, tile_rows, 0, world)
+    scatter_shard_into_frame(full, shard, height, width, tile_rows, 0, world, channels)
     for q in reqs:
         q.wait()
     for k in range(1, world):
-        scatter_shard_into_frame(full, bufs[k], height, width, tile_rows, k, world)
+        scatter_shard_into_frame(full, bufs[k], height, width, tile_rows, k, world, channels)
     return full
 
 
@@ -94,16 +96,18 @@ class TileExchange:
     `drain()` completes what is still in flight.  `depth == 1` is the serial gather.
     """
 
-    def __init__(self, dist, rank: int, world: int, height: int, width: int, tile_rows: int, alloc, depth: int = 2):
-        """`alloc(n_floats)` returns a float32 tensor on the device the exchange runs on."""
+    def __init__(self, dist, rank: int, world: int, height: int, width: int, tile_rows: int, alloc, depth: int = 2,
+                 channels: int = 3):
+        """`alloc(n)` returns a tensor of n elements on the device the exchange runs on: float32 with
+        channels = 3 (RGB frames), a 32-bit integer type with channels = 1 (OUT_RGBA8 frames: a third of the bytes)."""
         self.dist, self.rank, self.world = dist, rank, world
-        self.h, self.w, self.tile_rows, self.depth = height, width, tile_rows, max(1, depth)
-        n = shard_rows(height, tile_rows, rank, world) * width * 3
+        self.h, self.w, self.tile_rows, self.depth, self.ch = height, width, tile_rows, max(1, depth), channels
+        n = shard_rows(height, tile_rows, rank, world) * width * channels
         self._shards = [alloc(n) for _ in range(self.depth)]
         self._sends = [None] * self.depth                    # rank != 0: the send using shard buffer k
         if rank == 0:
-            self._full = [alloc(height * width * 3) for _ in range(self.depth)]
-            self._recv = [[alloc(shard_rows(height, tile_rows, k, world) * width * 3) if k else None
+            self._full = [alloc(height * width * channels) for _ in range(self.depth)]
+            self._recv = [[alloc(shard_rows(height, tile_rows, k, world) * width * channels) if k else None
                            for k in range(world)] for _ in range(self.depth)]
             self._pending = []                               # [(frame, slot, [requests])] in frame order
 
@@ -117,13 +121,13 @@ class TileExchange:
     def submit(self, f: int):
         k = f % self.depth
         if self.world == 1:
-            scatter_shard_into_frame(self._full[k], self._shards[k], self.h, self.w, self.tile_rows, 0, 1)
+            scatter_shard_into_frame(self._full[k], self._shards[k], self.h, self.w, self.tile_rows, 0, 1, self.ch)
             return [(f, self._full[k])]
         if self.rank != 0:
             self._sends[k] = self.dist.isend(self._shards[k], dst=0)
             return []
         reqs = [self.dist.irecv(self._recv[k][src], src=src) for src in range(1, self.world)]
-        scatter_shard_into_frame(self._full[k], self._shards[k], self.h, self.w, self.tile_rows, 0, self.world)
+        scatter_shard_into_frame(self._full[k], self._shards[k], self.h, self.w, self.tile_rows, 0, self.world, self.ch)
         self._pending.append((f, k, reqs))
         return self._complete(keep=self.depth - 1)
 
@@ -134,7 +138,7 @@ class TileExchange:
             for q in reqs:
                 q.wait()
             for src in range(1, self.world):
-                scatter_shard_into_frame(self._full[k], self._recv[k][src], self.h, self.w, self.tile_rows, src, self.world)
+                scatter_shard_into_frame(self._full[k], self._recv[k][src], self.h, self.w, self.tile_rows, src, self.world, self.ch)
             done.append((f, self._full[k]))
         return done
 

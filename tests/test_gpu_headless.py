@@ -81,6 +81,8 @@ def test_bench_row_tile_mode_two_ranks_on_one_gpu():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["parallelism"] == "row tiles x2"
     assert d["config"]["width"] == 7680 and d["config"]["height"] == 4320
-    assert d["gather_check"].startswith("bit-identical")
-    assert d["roofline"]["frac"] > 0 and d["roofline"]["kernel_ms"] > 0 and d["exchange"]["shard_MB"] > 190
+    assert d["gather_check"].startswith("bit-identical") and d["gather_check"].endswith("= unorm8 of the binary32 frame")
+    assert d["exchange"]["format"] == "rgba8" and 60 < d["exchange"]["shard_MB"] < 70          # 7680 x 2160 rows x 4 B
+    assert d["exchange_other_format"]["format"] == "f32" and d["exchange_other_format"]["shard_MB"] > 190
+    assert d["roofline"]["frac"] > 0 and d["roofline"]["kernel_ms"] > 0
     assert d["single_gpu"]["ms_per_frame"] > 0 and d["value"] > 0

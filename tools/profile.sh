@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/profile.sh <round-tag> — run on the GPU box (gpurun).  For the headline workload (room800) and the
-# LBVH workload (spheres800) it collects, each in a run of its own:
+# tree workloads (spheres800, spheres4k) it collects, each in a run of its own:
 #   (1) rocprofv3 --kernel-trace --stats of the bench command            -> <tag>_<w>_kernel_stats.csv
 #   (2) HBM traffic: FETCH_SIZE and WRITE_SIZE in separate --pmc passes   -> traffic.json (bytes per launch)
 #   (3) SQ instruction and wait counters                                  -> <tag>_<w>_pmc.json
@@ -10,7 +10,7 @@ tag=${1:-r02}
 out=gpurun_out/profiles_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-for w in room800 spheres800; do
+for w in room800 spheres800 spheres4k; do
   args="--steps 8 --warmup 2 --no-cpu --no-configs --workload $w"
   timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_$w -o $w -- python3 bench.py $args > $out/${tag}_${w}_bench_under_rocprof.json 2> $out/trace_$w.err || exit 1
   cp $out/trace_$w/${w}_kernel_stats.csv $out/${tag}_${w}_kernel_stats.csv
@@ -28,7 +28,12 @@ python3 - $out $tag <<'PY'
 import csv, sys, json, collections, glob, os
 out, tag = sys.argv[1], sys.argv[2]
 traffic, issued = {}, {}
-for w, kern in (("room800", "render_lockstep_kernel<0>"), ("spheres800", "render_lockstep_kernel<3>")):
+for w in ("room800", "spheres800", "spheres4k"):
+    # the dominant kernel of the run: the render kernel with the largest total time in the kernel trace
+    # (room800: render_lockstep_kernel<0>; the tree scenes: <2> walked per lane or <3> by packets, as the launcher chose)
+    rows = [r for r in csv.DictReader(open(os.path.join(out, "%s_%s_kernel_stats.csv" % (tag, w)))) if "render_lockstep_kernel" in r["Name"]]
+    kern = max(rows, key=lambda r: float(r["TotalDurationNs"]))["Name"]
+    kern = kern[kern.index("render_lockstep_kernel"):].split("(")[0]
     acc = collections.defaultdict(list)
     for f in glob.glob(os.path.join(out, "pmc_%s_*" % w, "p_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
@@ -65,4 +70,4 @@ for w, kern in (("room800", "render_lockstep_kernel<0>"), ("spheres800", "render
 json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 json.dump(issued, open(os.path.join(out, "issued.json"), "w"), indent=1)
 PY
-for w in room800 spheres800; do cat $out/${tag}_${w}_kernel_stats.csv; done
+for w in room800 spheres800 spheres4k; do cat $out/${tag}_${w}_kernel_stats.csv; done
