@@ -64,7 +64,7 @@ def test_row_tile_gather_equals_single_rank(oracle, tmp_path, world, height, wid
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
-def _pipeline_worker(rank, world, port, height, width, tile_rows, depth, n_frames, out_path):
+def _pipeline_worker(rank, world, port, height, width, tile_rows, depth, n_frames, out_path, rgba8=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -74,20 +74,27 @@ def _pipeline_worker(rank, world, port, height, width, tile_rows, depth, n_frame
     desc = scenes.room(width, height)
     tris, lights = pyoracle.build_scene(desc)
     cams, trs = api.camera_sweep(n_frames, desc.cam_pos, desc.cam_rot)
-    ex = sharding.TileExchange(dist, rank, world, height, width, tile_rows, lambda n: torch.zeros(n), depth=depth)
+    if rgba8:     # OUT_RGBA8 frames travel as one 32-bit element per pixel
+        ex = sharding.TileExchange(dist, rank, world, height, width, tile_rows, lambda n: torch.zeros(n, dtype=torch.int32), depth=depth, channels=1)
+    else:
+        ex = sharding.TileExchange(dist, rank, world, height, width, tile_rows, lambda n: torch.zeros(n), depth=depth)
     frames = {}
 
     def keep(done):
         for f, full in done:
             assert f not in frames
-            frames[f] = full.numpy().reshape(height, width, 3).copy()    # the buffer is reused `depth` frames later
+            frames[f] = full.numpy().reshape(height, width, 1 if rgba8 else 3).copy()    # the buffer is reused `depth` frames later
 
     for f in range(n_frames):
         buf = ex.shard(f)
         parts = []
         for r0, r1 in sharding.shard_tiles(height, tile_rows, rank, world):
             img = pyoracle.render(tris, lights, cams[f], trs[f], width, height, desc.depth, rows=(r0, r1, 1))
-            parts.append(img[r0:r1].reshape(-1))
+            part = img[r0:r1]
+            if rgba8:
+                q = pyoracle.quantize(part).reshape(r1 - r0, width, 3)
+                part = np.concatenate([q, np.full((r1 - r0, width, 1), 255, np.uint8)], axis=2).view(np.int32)
+            parts.append(part.reshape(-1))
         if parts:
             buf.copy_(torch.from_numpy(np.concatenate(parts)))
         keep(ex.submit(f))
@@ -114,6 +121,23 @@ def test_pipelined_tile_exchange_equals_single_rank(oracle, tmp_path, world, dep
     for f in range(n_frames):
         want = oracle.render(tris, lights, cams[f], trs[f], width, height, desc.depth)
         assert np.array_equal(got[f].view(np.uint32), want.view(np.uint32)), f
+
+
+def test_pipelined_exchange_of_8bit_frames(oracle, tmp_path):
+    """The same exchange with RT_OUT_RGBA8 frames (one 32-bit element per pixel, a third of the bytes): every
+    gathered frame is the quantised single-rank frame."""
+    from raytracing_amd import api, scenes
+    height, width, tile_rows, n_frames, world = 40, 24, 8, 4, 3
+    out_path = str(tmp_path / "frames8.npy")
+    mp.spawn(_pipeline_worker, args=(world, _free_port(), height, width, tile_rows, 2, n_frames, out_path, True), nprocs=world, join=True)
+    got = np.load(out_path)
+    desc = scenes.room(width, height)
+    tris, lights = oracle.build_scene(desc)
+    cams, trs = api.camera_sweep(n_frames, desc.cam_pos, desc.cam_rot)
+    for f in range(n_frames):
+        want = oracle.quantize(oracle.render(tris, lights, cams[f], trs[f], width, height, desc.depth)).reshape(height, width, 3)
+        g = got[f].view(np.uint8).reshape(height, width, 4)
+        assert np.array_equal(g[..., :3], want) and (g[..., 3] == 255).all(), f
 
 
 def test_tile_partition_matches_c_abi():

@@ -12,7 +12,8 @@ mkdir -p $out
 export TMPDIR=/tmp
 for w in room800 spheres800 spheres4k; do
   args="--steps 8 --warmup 2 --no-cpu --no-configs --workload $w"
-  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_$w -o $w -- python3 bench.py $args > $out/${tag}_${w}_bench_under_rocprof.json 2> $out/trace_$w.err || exit 1
+  # (the kernel trace runs the default step counts, so that its average is over launches at steady clocks like bench.py's own)
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_$w -o $w -- python3 bench.py --steps 20 --warmup 5 --no-cpu --no-configs --workload $w > $out/${tag}_${w}_bench_under_rocprof.json 2> $out/trace_$w.err || exit 1
   cp $out/trace_$w/${w}_kernel_stats.csv $out/${tag}_${w}_kernel_stats.csv
   i=0
   for pass in "FETCH_SIZE" "WRITE_SIZE" \
