@@ -13,7 +13,7 @@
 // quad shows.  8-bit values use the GL unorm rule q = (int)(c*255.0f + 0.5f).
 //
 //   rt_headless [--scene stock|FILE] [--size W H] [--depth D] [--camera px py pz rx ry rz]
-//               [--frames N] [--async] [--lbvh|--brute] [--device K]
+//               [--frames N] [--async] [--rgba8] [--lbvh|--brute] [--device K]
 //               [--txt Image.txt] [--ppm out.ppm] [--raw out.f32] [--rto model.rto]
 //               [--walk SCRIPT]
 //
@@ -43,6 +43,7 @@ struct Options {
 	float cam[6] = { -5, 5, 5, 135, -45, 0 };   // Source.cpp:810
 	bool cam_set = false;
 	int frames = 1;
+	bool rgba8 = false;         // --rgba8: frames as RT_OUT_RGBA8 pixels (the 8 bits GL makes of `data`); images are written from them, --raw dumps them
 	bool pipelined = false;     // --async: rt_render_async into two pinned frames (the hand-off of Source.cpp:1270 overlapped with the next render)
 	int accel = RT_ACCEL_AUTO;
 	int device = 0;
@@ -124,14 +125,17 @@ unsigned char q8(float c) {
 	return (unsigned char)(int)(c * 255.0f + 0.5f);
 }
 
-bool write_image(const std::string& path, const std::vector<float>& data, int w, int h, bool text) {
+// `data` holds float RGB, or (rgba8) one packed R, G, B, 255 pixel per float slot as RT_OUT_RGBA8 frames do
+bool write_image(const std::string& path, const std::vector<float>& data, int w, int h, bool text, bool rgba8) {
 	FILE* f = fopen(path.c_str(), text ? "w" : "wb");
 	if (!f) return false;
 	fprintf(f, "%s\n%d %d\n255\n", text ? "P3" : "P6", w, h);
+	const unsigned char* bytes = (const unsigned char*)data.data();
 	for (int y = h - 1; y >= 0; y--)
 		for (int x = 0; x < w; x++) {
-			const float* p = &data[((size_t)y * w + x) * 3];
-			unsigned char rgb[3] = { q8(p[0]), q8(p[1]), q8(p[2]) };
+			unsigned char rgb[3];
+			if (rgba8) memcpy(rgb, bytes + ((size_t)y * w + x) * 4, 3);
+			else { const float* p = &data[((size_t)y * w + x) * 3]; rgb[0] = q8(p[0]); rgb[1] = q8(p[1]); rgb[2] = q8(p[2]); }
 			if (text) fprintf(f, "%d %d %d\n", rgb[0], rgb[1], rgb[2]);
 			else fwrite(rgb, 1, 3, f);
 		}
@@ -151,6 +155,7 @@ int main(int argc, char** argv) {
 		else if (a == "--camera") { need(6); for (int k = 0; k < 6; k++) o.cam[k] = strtof(argv[++i], nullptr); o.cam_set = true; }
 		else if (a == "--frames") { need(1); o.frames = atoi(argv[++i]); }
 		else if (a == "--async") o.pipelined = true;
+		else if (a == "--rgba8") o.rgba8 = true;
 		else if (a == "--lbvh") o.accel = RT_ACCEL_LBVH;
 		else if (a == "--brute") o.accel = RT_ACCEL_BRUTE;
 		else if (a == "--device") { need(1); o.device = atoi(argv[++i]); }
@@ -201,7 +206,8 @@ int main(int argc, char** argv) {
 	rt_camera camera;
 	rt_camera_init(&camera, o.cam, o.cam + 3);                          // Source.cpp:810
 	float trans[16];
-	const size_t n_floats = (size_t)o.width * o.height * 3;
+	const size_t n_floats = (size_t)o.width * o.height * (o.rgba8 ? 1 : 3);      // RT_OUT_RGBA8: one 4-byte pixel instead of three floats
+	const int flags = RT_RENDER_STRICT | (o.rgba8 ? RT_OUT_RGBA8 : 0);
 	std::vector<float> data;                                            // Source.cpp:1035
 	float* pinned[2] = { nullptr, nullptr };
 	try {
@@ -222,10 +228,10 @@ int main(int argc, char** argv) {
 		rt_camera_trans(camera.rotations, trans);                       // Source.cpp:1145-1147
 		if (o.pipelined) {
 			// frame f renders and copies while the caller still holds frame f-1 (what a viewer would be uploading)
-			ticket[f & 1] = rt_render_async(s, camera.position, trans, o.width, o.height, o.depth, RT_RENDER_STRICT, pinned[f & 1]);
+			ticket[f & 1] = rt_render_async(s, camera.position, trans, o.width, o.height, o.depth, flags, pinned[f & 1]);
 			if (ticket[f & 1] < 0) { fail("rt_render_async"); rt_scene_destroy(s); return 1; }
 			if (f > 0 && rt_render_wait(s, ticket[(f - 1) & 1]) != RT_OK) { fail("rt_render_wait"); rt_scene_destroy(s); return 1; }
-		} else if (rt_render(s, camera.position, trans, o.width, o.height, o.depth, RT_RENDER_STRICT, data.data()) != RT_OK) { fail("rt_render"); rt_scene_destroy(s); return 1; }
+		} else if (rt_render(s, camera.position, trans, o.width, o.height, o.depth, flags, data.data()) != RT_OK) { fail("rt_render"); rt_scene_destroy(s); return 1; }
 		if (!keys.empty()) rt_camera_step(&camera, keys[f], key_ms[f]); // Source.cpp:1294-1295, 1307-1308 (scripted frame time)
 		auto t1 = std::chrono::steady_clock::now();
 		double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
@@ -242,8 +248,8 @@ int main(int argc, char** argv) {
 		printf("camera after the walk: position %.9g %.9g %.9g rotations %.9g %.9g %.9g\n", camera.position[0], camera.position[1],
 		       camera.position[2], camera.rotations[0], camera.rotations[1], camera.rotations[2]);
 	bool ok = true;
-	if (!o.txt.empty()) ok = write_image(o.txt, data, o.width, o.height, true) && ok;
-	if (!o.ppm.empty()) ok = write_image(o.ppm, data, o.width, o.height, false) && ok;
+	if (!o.txt.empty()) ok = write_image(o.txt, data, o.width, o.height, true, o.rgba8) && ok;
+	if (!o.ppm.empty()) ok = write_image(o.ppm, data, o.width, o.height, false, o.rgba8) && ok;
 	if (!o.raw.empty()) {
 		FILE* f = fopen(o.raw.c_str(), "wb");
 		ok = f && fwrite(data.data(), sizeof(float), data.size(), f) == data.size() && ok;

@@ -51,6 +51,15 @@ def test_headless_walk_equals_oracle(tmp_path, oracle):
     res = subprocess.run([EXE, "--scene", str(scene), "--walk", str(walk), "--raw", str(raw2), "--async"], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stderr
     assert np.array_equal(_bits(np.fromfile(raw2, dtype=np.float32).reshape(desc.height, desc.width, 3)), _bits(want))
+    # the same walk with 8-bit frames (RT_OUT_RGBA8) through the pipelined hand-off: the P6 image is the quantised oracle frame
+    ppm8 = tmp_path / "out8.ppm"
+    res = subprocess.run([EXE, "--scene", str(scene), "--walk", str(walk), "--ppm", str(ppm8), "--async", "--rgba8"], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    blob = ppm8.read_bytes()
+    head = ("P6\n%d %d\n255\n" % (desc.width, desc.height)).encode()
+    assert blob.startswith(head)
+    px8 = np.frombuffer(blob[len(head):], dtype=np.uint8).reshape(desc.height, desc.width, 3)
+    assert np.array_equal(px8[::-1], oracle.quantize(want).reshape(desc.height, desc.width, 3))
     bad = subprocess.run([EXE, "--scene", str(scene), "--size", "-5", "64"], capture_output=True, text=True, timeout=60)
     assert bad.returncode == 2 and "not usable" in bad.stderr                     # (used to abort on the allocation)
 
