@@ -12,13 +12,13 @@ typedef unsigned long long u64;
 
 namespace {
 // ---- the tree's topology by binned surface-area heuristic, on the host (rt_scene_set_build RT_BUILD_SAH) ----
-// The Morton/Karras tree above is built in half a millisecond but splits space at the planes of a fixed
+// The Morton/Karras tree (rt_lbvh.hip) is built in half a millisecond but splits space at the planes of a fixed
 // grid; a top-down build that picks, per node, the plane that minimises area(L) * count(L) + area(R) * count(R)
 // over 16 bins on each axis (Wald 2007) gives a tree a ray crosses in fewer nodes (sum of child-box areas over
-// the root's: 8.7 instead of 10.7 for the 102k-triangle scene) at the price of tens of milliseconds of host
-// time per commit — the choice for a scene that is committed once and rendered for many frames.
+// the root's: 8.7 instead of 10.7 for the 102k-triangle scene) at the price of 15-45 ms of host time per 100k
+// triangles and commit — the choice for a scene that is committed once and rendered for many frames.
 // Only the TOPOLOGY is made here, in the arrays k_karras writes on the GPU: child references, parent links and
-// the leaf order; boxes, the 4-wide collapse, packet records and hoisting are the same kernels as above.
+// the leaf order; boxes, the 4-wide collapse, packet records and hoisting are rt_lbvh.hip's kernels either way.
 // Numbering: inner nodes in depth-first preorder (a subtree of m leaves owns m-1 consecutive node indices, its
 // leaves m consecutive positions), so both halves of a split know their index ranges before they are built and
 // large subtrees are built on separate threads.  Depth: below RT_SAH_MEDIAN_DEPTH levels splits fall back to

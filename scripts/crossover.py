@@ -6,7 +6,7 @@ from raytracing_amd import api, scenes
 W = H = 800
 NF = 32
 out = torch.empty((NF, H, W, 3), dtype=torch.float32, device="cuda:0")
-for (ns, sub) in [(2, 1), (4, 1), (6, 1), (8, 1), (12, 1), (6, 2), (20, 1), (10, 2), (20, 2), (20, 3)]:
+for (ns, sub) in [tuple(map(int, a.split(","))) for a in sys.argv[1:]] or [(2, 1), (4, 1), (6, 1), (8, 1), (12, 1), (6, 2), (20, 1), (10, 2), (20, 2), (20, 3)]:
     desc = scenes.spheres(ns, sub, W, H)
     cams = np.tile(np.asarray(desc.cam_pos, np.float32), (NF, 1))
     trs = np.tile(api.camera_trans(desc.cam_rot).astype(np.float32).reshape(1, 16), (NF, 1))

@@ -242,7 +242,7 @@ def test_lbvh_100k_rays_equal_brute():
 
 
 def test_auto_picks_lbvh_above_threshold():
-    with api.Scene.from_desc(scenes.spheres(4, 2, 8, 8)) as sc:       # 1292 triangles (> RT_BRUTE_AUTO_MAX = 128)
+    with api.Scene.from_desc(scenes.spheres(4, 2, 8, 8)) as sc:       # 1292 triangles (> RT_BRUTE_AUTO_MAX = 40)
         sc.commit(0, api.ACCEL_AUTO)
         assert sc.accel(0) == api.ACCEL_LBVH
     with api.Scene.from_desc(scenes.stock(8, 8)) as sc:
