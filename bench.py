@@ -500,7 +500,7 @@ def run_tile_mode(args, api, torch, dist, rank, world, dev, on_gpu, name):
                        "rays_per_frame_mean": rays / args.steps, "parallelism": "row tiles x%d" % world,
                        "output": ("packed 8-bit RGBA pixels (RT_OUT_RGBA8: the GL unorm conversion of the binary32 colour, what the reference's viewer displays)"
                                   if fmt == "rgba8" else "binary32 RGB (the reference's `data`)"),
-                       "exchange": "point-to-point sends of the compact %s shards to rank 0 (%s), two shard buffers per rank" % (fmt, args.backend)},
+                       "exchange": "one non-blocking gather of the compact %s shards to rank 0 per frame (%s; shards padded to a common size), two shard buffers per rank" % (fmt, args.backend)},
             "roofline": roofline_of(flops / args.steps * share, kernel_ms, 1, args.steps, name),
             "exchange": {"format": fmt, "kernel_ms_rank0": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
                          "non_render_ms_per_frame": wall / args.steps * 1e3 - kernel_ms_max,

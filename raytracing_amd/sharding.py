@@ -81,6 +81,30 @@ def gather_frame(dist, shard, full, rank: int, world: int, height: int, width: i
     return full
 
 
+def scatter_all_into_frame(full, recv, height: int, width: int, tile_rows: int, world: int, channels: int, pitch: int) -> None:
+    """De-interleave the shards of ALL ranks at once: `recv` holds rank r's compact shard at elements
+    [r*pitch, r*pitch + its size) (what a gather of equally padded shards leaves on rank 0).  The tile groups in
+    which every rank has a whole tile move in ONE strided copy, the ragged tail in one more (plus one for a last,
+    shorter tile) — two or three device operations per frame instead of one or two per rank."""
+    e = tile_rows * width * channels                     # elements of a whole tile
+    n_tiles = (height + tile_rows - 1) // tile_rows
+    g_full = (height // tile_rows) // world              # groups of `world` whole tiles
+    rv = recv.reshape(-1)[: world * pitch].reshape(world, pitch)
+    fv = full.reshape(-1)
+    if g_full > 0:
+        fv[: g_full * world * e].reshape(g_full, world, e)[...] = rv[:, : g_full * e].reshape(world, g_full, e).swapaxes(0, 1)
+    tail = n_tiles - g_full * world                      # tiles of the last, incomplete group: ranks 0 .. tail-1, local tile g_full
+    if tail > 0:
+        last_rows = height - (n_tiles - 1) * tile_rows   # rows of the very last tile (== tile_rows unless the height is ragged)
+        whole = tail if last_rows == tile_rows else tail - 1
+        base = g_full * world * e
+        if whole > 0:
+            fv[base: base + whole * e].reshape(whole, e)[...] = rv[:whole, g_full * e: (g_full + 1) * e]
+        if whole < tail:
+            n = last_rows * width * channels
+            fv[base + whole * e: base + whole * e + n] = rv[whole, g_full * e: g_full * e + n]
+
+
 class TileExchange:
     """Pipelined form of :func:`gather_frame` for a sequence of frames: `depth` shard buffers per
     rank, so that frame f+1 is rendered while frame f is still on its way to rank 0.
@@ -94,57 +118,88 @@ class TileExchange:
     `submit` on rank 0 returns the list of (frame index, full frame) that became complete with this
     call (frames complete in order, one call late at most `depth - 1` frames); other ranks get [].
     `drain()` completes what is still in flight.  `depth == 1` is the serial gather.
+
+    The exchange of a frame is ONE non-blocking `gather` to rank 0 (RCCL runs it as grouped sends and
+    receives: the 7 transfers into GPU 0 use their xGMI links concurrently): every rank's shard buffer is padded
+    to the size of the largest shard so that the pieces are equal, and rank 0 de-interleaves all of them with
+    :func:`scatter_all_into_frame` — per frame one collective call and two or three copies on rank 0,
+    whatever the number of ranks.
     """
 
     def __init__(self, dist, rank: int, world: int, height: int, width: int, tile_rows: int, alloc, depth: int = 2,
-                 channels: int = 3):
+                 channels: int = 3, collective: bool = True):
         """`alloc(n)` returns a tensor of n elements on the device the exchange runs on: float32 with
-        channels = 3 (RGB frames), a 32-bit integer type with channels = 1 (OUT_RGBA8 frames: a third of the bytes)."""
+        channels = 3 (RGB frames), a 32-bit integer type with channels = 1 (OUT_RGBA8 frames: a third of the bytes).
+        collective=False exchanges by point-to-point sends and receives instead of the gather (also the fallback
+        when the backend has no gather)."""
         self.dist, self.rank, self.world = dist, rank, world
         self.h, self.w, self.tile_rows, self.depth, self.ch = height, width, tile_rows, max(1, depth), channels
-        n = shard_rows(height, tile_rows, rank, world) * width * channels
-        self._shards = [alloc(n) for _ in range(self.depth)]
-        self._sends = [None] * self.depth                    # rank != 0: the send using shard buffer k
+        self.n = shard_rows(height, tile_rows, rank, world) * width * channels
+        self.pitch = max(shard_rows(height, tile_rows, k, world) for k in range(world)) * width * channels
+        self._shards = [alloc(self.pitch) for _ in range(self.depth)]
+        self._work = [None] * self.depth                     # the gather that reads shard buffer k
+        self._use_gather = bool(collective)
         if rank == 0:
             self._full = [alloc(height * width * channels) for _ in range(self.depth)]
-            self._recv = [[alloc(shard_rows(height, tile_rows, k, world) * width * channels) if k else None
-                           for k in range(world)] for _ in range(self.depth)]
-            self._pending = []                               # [(frame, slot, [requests])] in frame order
+            self._recv = [alloc(world * self.pitch) for _ in range(self.depth)] if world > 1 else None
+            self._pending = []                               # [(frame, slot)] in frame order
 
     def shard(self, f: int):
+        """This rank's compact buffer for frame f (its first shard_rows * width * channels elements are the shard)."""
         k = f % self.depth
-        if self._sends[k] is not None:                       # the buffer is free once its last send is done
-            self._sends[k].wait()
-            self._sends[k] = None
-        return self._shards[k]                              # (rank 0: slot k's frame was completed by an earlier submit)
+        if self._work[k] is not None:                        # the buffer is free once the gather that reads it is done
+            self._work[k].wait()
+            self._work[k] = None
+        return self._shards[k][: self.n]                     # (rank 0: slot k's frame was completed by an earlier submit)
 
     def submit(self, f: int):
         k = f % self.depth
         if self.world == 1:
-            scatter_shard_into_frame(self._full[k], self._shards[k], self.h, self.w, self.tile_rows, 0, 1, self.ch)
+            scatter_shard_into_frame(self._full[k], self._shards[k][: self.n], self.h, self.w, self.tile_rows, 0, 1, self.ch)
             return [(f, self._full[k])]
+        pieces = None
+        if self.rank == 0:
+            pieces = [self._recv[k][r * self.pitch: (r + 1) * self.pitch] for r in range(self.world)]
+        if self._use_gather:
+            try:
+                self._work[k] = self.dist.gather(self._shards[k], pieces, dst=0, async_op=True)
+            except (RuntimeError, NotImplementedError):      # a backend without gather: every rank lands here alike
+                self._use_gather = False
+        if not self._use_gather:
+            self._work[k] = self._point_to_point(k, pieces)
         if self.rank != 0:
-            self._sends[k] = self.dist.isend(self._shards[k], dst=0)
             return []
-        reqs = [self.dist.irecv(self._recv[k][src], src=src) for src in range(1, self.world)]
-        scatter_shard_into_frame(self._full[k], self._shards[k], self.h, self.w, self.tile_rows, 0, self.world, self.ch)
-        self._pending.append((f, k, reqs))
+        self._pending.append((f, k))
         return self._complete(keep=self.depth - 1)
+
+    def _point_to_point(self, k: int, pieces):
+        """The same exchange as non-blocking sends to rank 0 and one receive per peer there."""
+        if self.rank != 0:
+            return self.dist.isend(self._shards[k], dst=0)
+        reqs = [self.dist.irecv(pieces[src], src=src) for src in range(1, self.world)]
+        pieces[0][...] = self._shards[k]
+
+        class _All:
+            def wait(_self):
+                for q in reqs:
+                    q.wait()
+        return _All()
 
     def _complete(self, keep: int):
         done = []
         while self.rank == 0 and len(self._pending) > keep:
-            f, k, reqs = self._pending.pop(0)
-            for q in reqs:
-                q.wait()
-            for src in range(1, self.world):
-                scatter_shard_into_frame(self._full[k], self._recv[k][src], self.h, self.w, self.tile_rows, src, self.world, self.ch)
+            f, k = self._pending.pop(0)
+            if self._work[k] is not None:
+                self._work[k].wait()
+                self._work[k] = None
+            scatter_all_into_frame(self._full[k], self._recv[k], self.h, self.w, self.tile_rows, self.world, self.ch, self.pitch)
             done.append((f, self._full[k]))
         return done
 
     def drain(self):
+        done = self._complete(keep=0) if self.rank == 0 and self.world > 1 else []
         for k in range(self.depth):
-            if self._sends[k] is not None:
-                self._sends[k].wait()
-                self._sends[k] = None
-        return self._complete(keep=0) if self.rank == 0 else []
+            if self._work[k] is not None:
+                self._work[k].wait()
+                self._work[k] = None
+        return done

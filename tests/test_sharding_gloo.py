@@ -64,7 +64,7 @@ def test_row_tile_gather_equals_single_rank(oracle, tmp_path, world, height, wid
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
-def _pipeline_worker(rank, world, port, height, width, tile_rows, depth, n_frames, out_path, rgba8=False):
+def _pipeline_worker(rank, world, port, height, width, tile_rows, depth, n_frames, out_path, rgba8=False, collective=True):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -77,7 +77,7 @@ def _pipeline_worker(rank, world, port, height, width, tile_rows, depth, n_frame
     if rgba8:     # OUT_RGBA8 frames travel as one 32-bit element per pixel
         ex = sharding.TileExchange(dist, rank, world, height, width, tile_rows, lambda n: torch.zeros(n, dtype=torch.int32), depth=depth, channels=1)
     else:
-        ex = sharding.TileExchange(dist, rank, world, height, width, tile_rows, lambda n: torch.zeros(n), depth=depth)
+        ex = sharding.TileExchange(dist, rank, world, height, width, tile_rows, lambda n: torch.zeros(n), depth=depth, collective=collective)
     frames = {}
 
     def keep(done):
@@ -106,14 +106,15 @@ def _pipeline_worker(rank, world, port, height, width, tile_rows, depth, n_frame
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,depth", [(2, 2), (3, 2), (2, 1), (2, 3)])
-def test_pipelined_tile_exchange_equals_single_rank(oracle, tmp_path, world, depth):
+@pytest.mark.parametrize("world,depth,collective", [(2, 2, True), (3, 2, True), (2, 1, True), (2, 3, True), (3, 2, False)])
+def test_pipelined_tile_exchange_equals_single_rank(oracle, tmp_path, world, depth, collective):
     """TileExchange: shards of frame f+1 are produced while frame f is in flight; every completed
-    frame equals the single-rank frame of its pose, in order, whatever the pipeline depth."""
+    frame equals the single-rank frame of its pose, in order, whatever the pipeline depth — by one gather per
+    frame, and by point-to-point sends (the fallback)."""
     from raytracing_amd import api, scenes
     height, width, tile_rows, n_frames = 40, 24, 8, 5
     out_path = str(tmp_path / "frames.npy")
-    mp.spawn(_pipeline_worker, args=(world, _free_port(), height, width, tile_rows, depth, n_frames, out_path), nprocs=world, join=True)
+    mp.spawn(_pipeline_worker, args=(world, _free_port(), height, width, tile_rows, depth, n_frames, out_path, False, collective), nprocs=world, join=True)
     got = np.load(out_path)
     desc = scenes.room(width, height)
     tris, lights = oracle.build_scene(desc)
@@ -159,6 +160,27 @@ def test_scatter_numpy_all_shapes():
             shard = np.concatenate([want[a:b].reshape(-1) for a, b in tiles]) if tiles else np.zeros(0, np.float32)
             sharding.scatter_shard_into_frame(full, shard, h, w, tr, k, n)
         assert np.array_equal(full.reshape(h, w * 3), want)
+
+
+def test_scatter_all_shapes_at_once():
+    """scatter_all_into_frame: the shards of all ranks, padded to a common pitch as the gather leaves them, land
+    in the frame in two or three copies — whole groups, ragged tail, short last tile; numpy and torch alike."""
+    rng = np.random.default_rng(1)
+    for h, w, tr, n, ch in [(64, 5, 8, 4, 3), (70, 3, 8, 4, 3), (9, 2, 16, 2, 1), (33, 4, 1, 5, 3), (4320, 3, 16, 8, 1),
+                            (40, 24, 8, 3, 3), (100, 3, 7, 3, 1), (5, 2, 16, 4, 3)]:
+        want = rng.integers(0, 1 << 30, (h, w * ch)).astype(np.int32)
+        pitch = max(sharding.shard_rows(h, tr, k, n) for k in range(n)) * w * ch
+        recv = np.full(n * pitch, -1, np.int32)
+        for k in range(n):
+            tiles = sharding.shard_tiles(h, tr, k, n)
+            sh = np.concatenate([want[a:b].reshape(-1) for a, b in tiles]) if tiles else np.zeros(0, np.int32)
+            recv[k * pitch: k * pitch + sh.size] = sh
+        full = np.zeros(h * w * ch, np.int32)
+        sharding.scatter_all_into_frame(full, recv, h, w, tr, n, ch, pitch)
+        assert np.array_equal(full.reshape(h, w * ch), want), (h, w, tr, n, ch)
+        tfull = torch.zeros(h * w * ch, dtype=torch.int32)
+        sharding.scatter_all_into_frame(tfull, torch.from_numpy(recv), h, w, tr, n, ch, pitch)
+        assert np.array_equal(tfull.numpy().reshape(h, w * ch), want), (h, w, tr, n, ch)
 
 
 def test_frames_round_robin():
