@@ -37,7 +37,7 @@ extern "C" {
 /* rt_scene_commit flags: acceleration structure */
 #define RT_ACCEL_AUTO    0   /* brute force up to RT_BRUTE_AUTO_MAX triangles, LBVH above */
 #define RT_ACCEL_BRUTE   1   /* the reference's O(N) loop over every triangle (Src:301)   */
-#define RT_ACCEL_LBVH    2   /* GPU-built Morton/Karras LBVH                              */
+#define RT_ACCEL_LBVH    2   /* bounding-volume tree over the triangles (rt_scene_set_build)  */
 #define RT_BRUTE_AUTO_MAX 40    /* measured at 800x800, us/frame brute | tree (SAH build): room (26 triangles) 17.8 | 23.5, 32: 12.2 | 14.5, 52: 14.1 | 13.0, 92: 17.8 | 13.6, 172: 20.4 | 13.8, 972: 36 | 18 */
 
 /* rt_render* flags: the only mode is unfused IEEE binary32 in the reference's operation order —
