@@ -304,6 +304,8 @@ int rt_scene_commit(rt_scene* s, int device, int accel_flags) {
 		d.oct_clusters = L.oct_clusters; d.oct_groups = L.oct_groups;
 		d.oct_cluster_pitch = L.oct_cluster_pitch; d.oct_group_pitch = L.oct_group_pitch;
 	} catch (...) { set_error("rt_scene_commit: out of host memory"); return RT_ERR_NOMEM; }
+	// (the render kernels address the scene as a 64-bit base + 32-bit byte offset, rt_kernels.hip c4ptr)
+	if (planes.size() * sizeof(float) >= 0xffffffffull) { set_error("rt_scene_commit: %d triangles need a scene buffer of 4 GiB or more", n); return RT_ERR_LIMIT; }
 	RT_HIP(hipMalloc(&d.planes, planes.size() * sizeof(float)));
 	RT_HIP(hipMemcpy(d.planes, planes.data(), planes.size() * sizeof(float), hipMemcpyHostToDevice));
 	RT_HIP(hipMalloc(&d.lights, (size_t)(nl > 0 ? nl : 1) * 4 * sizeof(float)));

@@ -188,11 +188,24 @@ __device__ __forceinline__ bool slab_hit(float4 lo, float4 hi, vec3 inv, vec3 oi
 // become s_load_*, their results live in SGPRs and feed the VALU as scalar operands); the scene is
 // read-only for the lifetime of a launch.
 typedef float v4f __attribute__((ext_vector_type(4)));
+// A wave-uniform 64-bit base plus a 32-bit byte offset: the form `s_load_dwordx4 sdst, sbase, soffset` takes, so
+// indexing costs one scalar shift/add per load instead of the four of a 64-bit address (sign extension, 64-bit
+// shift, add, add-with-carry).  Every buffer addressed this way is below 4 GiB (checked at commit).
 struct c4ptr {
-	const __attribute__((address_space(4))) v4f* p;
-	__device__ __forceinline__ float4 operator[](long long i) const { const v4f v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
-	__device__ __forceinline__ c4ptr offset_floats(long long f) const { c4ptr r; r.p = (const __attribute__((address_space(4))) v4f*)((const __attribute__((address_space(4))) float*)p + f); return r; }
+	const __attribute__((address_space(4))) char* p;
+	unsigned int off;
+	__device__ __forceinline__ float4 operator[](unsigned int i) const {
+		const v4f v = *(const __attribute__((address_space(4))) v4f*)(p + (off + i * 16u));
+		return make_float4(v.x, v.y, v.z, v.w);
+	}
+	__device__ __forceinline__ c4ptr offset_floats(unsigned int f) const { c4ptr r; r.p = p; r.off = off + f * 4u; return r; }
 };
+__device__ __forceinline__ c4ptr c4ptr_of(const void* base) {
+	c4ptr r;
+	r.p = (const __attribute__((address_space(4))) char*)(unsigned long long)base;
+	r.off = 0u;
+	return r;
+}
 
 // Slab test against an octant-ordered box record (near.xyz, far.xyz): for a wave whose rays all
 // point into the same octant the near/far faces are known per axis, so the per-axis min/max of
@@ -218,8 +231,8 @@ __device__ __forceinline__ Hit cast_ray_pruned(const DevScene& sc, c4ptr tri, in
 	h.p = make3(0.f, 0.f, 0.f);
 	float lim_hi = lim + fabsf(lim) * RT_PREFILTER_REL;
 	const float eps_lo = RT_EPS_BELOW * (1.0f - RT_PREFILTER_REL);
-	const c4ptr cbox = tri.offset_floats(sc.oct_clusters + (long long)oct * sc.oct_cluster_pitch * 8);
-	const c4ptr gbox = tri.offset_floats(sc.oct_groups + (long long)oct * sc.oct_group_pitch * 8);
+	const c4ptr cbox = tri.offset_floats((unsigned int)sc.oct_clusters + (unsigned int)oct * (unsigned int)sc.oct_cluster_pitch * 8u);
+	const c4ptr gbox = tri.offset_floats((unsigned int)sc.oct_groups + (unsigned int)oct * (unsigned int)sc.oct_group_pitch * 8u);
 	for (int c = 0; c < n_clusters; c++) {
 		// one record per cluster: its box and its run of groups.  A cluster of one group has that
 		// group's box, so its test stands for the group's and the group record is never fetched.
@@ -338,28 +351,24 @@ __device__ __forceinline__ Hit cast_ray_packet(const DevScene& sc, int oct, vec3
 	h.p = make3(0.f, 0.f, 0.f);
 	float lim_hi = lim + fabsf(lim) * RT_PREFILTER_REL;
 	const float eps_lo = RT_EPS_BELOW * (1.0f - RT_PREFILTER_REL);
-	c4ptr rec;
-	rec.p = (const __attribute__((address_space(4))) v4f*)(unsigned long long)sc.skiplist;
-	rec = rec.offset_floats((long long)oct * sc.skip_count * 16);
-	c4ptr aos;
-	aos.p = (const __attribute__((address_space(4))) v4f*)(unsigned long long)sc.tri_aos;
+	const c4ptr rec = c4ptr_of(sc.skiplist).offset_floats((unsigned int)oct * (unsigned int)sc.skip_count * 16u);
+	const c4ptr aos = c4ptr_of(sc.tri_aos);
 #ifdef RT_PROFILE
 	int steps_ = 0;
 #endif
 	if (sc.hoist_count > 0) {
 		// the triangles kept out of the tree (DevScene::hoist), each behind its octant-ordered box
-		c4ptr hrec;
-		hrec.p = (const __attribute__((address_space(4))) v4f*)(unsigned long long)sc.hoist;
-		const c4ptr hbox = hrec.offset_floats((long long)sc.hoist_count * 32 + (long long)oct * sc.hoist_count * 8);
+		const c4ptr hrec = c4ptr_of(sc.hoist);
+		const c4ptr hbox = hrec.offset_floats((unsigned int)sc.hoist_count * 32u + (unsigned int)oct * (unsigned int)sc.hoist_count * 8u);
 		for (int j = 0; j < sc.hoist_count;) {
-			const c4ptr R = hbox.offset_floats((long long)j * 8);
+			const c4ptr R = hbox.offset_floats((unsigned int)j * 8u);
 			const float4 a0 = R[0], a1 = R[1];
 			const int second = __float_as_int(a1.z);         // a partner with the same box follows (rt_lbvh.hip k_hoist), or -1
 			RT_PROF(wp, WP_INBOX);
 			if constexpr (COUNT) lc.box += lim >= 0.0f;
 			if (__builtin_amdgcn_ballot_w64(slab_hit_oct(a0, a1, inv, oi, lim_hi)) != 0) {
-				packet_leaf<COUNT>(hrec.offset_floats((long long)j * 32), __float_as_int(a1.w), o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp);
-				if (second >= 0) packet_leaf<COUNT>(hrec.offset_floats((long long)(j + 1) * 32), second, o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp);
+				packet_leaf<COUNT>(hrec.offset_floats((unsigned int)j * 32u), __float_as_int(a1.w), o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp);
+				if (second >= 0) packet_leaf<COUNT>(hrec.offset_floats((unsigned int)(j + 1) * 32u), second, o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp);
 			}
 			j += second >= 0 ? 2 : 1;
 		}
@@ -369,7 +378,7 @@ __device__ __forceinline__ Hit cast_ray_packet(const DevScene& sc, int oct, vec3
 	int sp = 0;
 	int node = 0;
 	for (;;) {
-		const c4ptr R = rec.offset_floats((long long)node * 16);
+		const c4ptr R = rec.offset_floats((unsigned int)node * 16u);
 		const float4 q0 = R[0], q1 = R[1], q2 = R[2], q3 = R[3];
 		const int refA = __float_as_int(q1.z), refB = __float_as_int(q1.w);
 		RT_PROF(wp, WP_GROUP);
@@ -377,14 +386,14 @@ __device__ __forceinline__ Hit cast_ray_packet(const DevScene& sc, int oct, vec3
 		const bool hitA = __builtin_amdgcn_ballot_w64(slab_hit_oct(q0, q1, inv, oi, lim_hi)) != 0;
 		int next = -1;
 		if (hitA) {
-			if (refA < 0) packet_leaf<COUNT>(aos.offset_floats((long long)(~refA) * 32), ~refA, o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp);
+			if (refA < 0) packet_leaf<COUNT>(aos.offset_floats((unsigned int)(~refA) * 32u), ~refA, o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp);
 			else next = refA;
 		}
 		// the farther child is tested after a near LEAF has had its chance to shorten the limits
 		if constexpr (COUNT) lc.box += lim >= 0.0f;
 		const bool hitB = __builtin_amdgcn_ballot_w64(slab_hit_oct(q2, q3, inv, oi, lim_hi)) != 0;
 		if (hitB) {
-			if (refB < 0) packet_leaf<COUNT>(aos.offset_floats((long long)(~refB) * 32), ~refB, o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp);
+			if (refB < 0) packet_leaf<COUNT>(aos.offset_floats((unsigned int)(~refB) * 32u), ~refB, o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp);
 			else if (next >= 0) wave_set_lane(stackv, refB, sp++);
 			else next = refB;
 		}
@@ -414,9 +423,8 @@ __device__ __forceinline__ Hit cast_ray_packet(const DevScene& sc, int oct, vec3
 template <bool COUNT>
 __device__ __forceinline__ void hoisted_tests(const DevScene& sc, vec3 o, vec3 d, vec3 inv, vec3 oi, int skip, bool live, bool first_only,
                                               Hit& h, float& lim, float& lim_hi, LaneCounters& lc, WaveProf& wp) {
-	c4ptr T;
-	T.p = (const __attribute__((address_space(4))) v4f*)(unsigned long long)sc.hoist;
-	c4ptr B = T.offset_floats((long long)sc.hoist_count * 32);                           // octant 0: near = lo, far = hi
+	c4ptr T = c4ptr_of(sc.hoist);
+	c4ptr B = T.offset_floats((unsigned int)sc.hoist_count * 32u);                           // octant 0: near = lo, far = hi
 	for (int j = 0; j < sc.hoist_count;) {
 		const float4 b0 = B[0], b1 = B[1];
 		const int second = __float_as_int(b1.z);             // a partner with the same box follows (rt_lbvh.hip k_hoist), or -1
@@ -663,8 +671,7 @@ __device__ __forceinline__ Hit trace(const DevScene& sc, const float4* lds_tri, 
 		const unsigned long long lv = __builtin_amdgcn_ballot_w64(live);
 		const int oct = (int)__builtin_amdgcn_readlane(lane_oct, lv ? __builtin_ctzll(lv) : 0);
 		const bool oct_uniform = __builtin_amdgcn_ballot_w64(live && (lane_oct != (unsigned int)oct || !near)) == 0ull;
-		c4ptr tri;
-		tri.p = (const __attribute__((address_space(4))) v4f*)(unsigned long long)sc.planes;
+		const c4ptr tri = c4ptr_of(sc.planes);
 		if constexpr (ACCEL == 0) {
 			if (oct_uniform) {
 				if (all_primary) return cast_ray_pruned<true, true>(sc, tri, oct, lds_num0, o, d, inv, oi, skip, lim, false, wp);
@@ -702,8 +709,7 @@ __device__ __forceinline__ Hit trace_brute(const DevScene& sc, const float* lds_
 	const unsigned long long lv = __builtin_amdgcn_ballot_w64(live);
 	const int oct = (int)__builtin_amdgcn_readlane(lane_oct, lv ? __builtin_ctzll(lv) : 0);
 	const bool oct_uniform = !some_far && __builtin_amdgcn_ballot_w64(live && lane_oct != (unsigned int)oct) == 0ull;
-	c4ptr tri;
-	tri.p = (const __attribute__((address_space(4))) v4f*)(unsigned long long)sc.planes;
+	const c4ptr tri = c4ptr_of(sc.planes);
 	constexpr bool first_only = KIND == RAY_SHADOW;
 	if (oct_uniform) {
 		if constexpr (KIND == RAY_PRIMARY && ACCEL == 0) return cast_ray_pruned<true, true>(sc, tri, oct, lds_num0, o, d, inv, oi, skip, lim, false, wp);
@@ -1040,8 +1046,7 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 	if (tile >= tile_end) return;
 	int ty = (int)(tile / (unsigned int)tiles_x), tx = (int)(tile - (unsigned int)ty * (unsigned int)tiles_x);
 	const int lx = (int)(threadIdx.x & (RT_TILE_W - 1)), lyi = (int)((threadIdx.x & 63u) / RT_TILE_W);
-	c4ptr lights;
-	lights.p = (const __attribute__((address_space(4))) v4f*)(unsigned long long)sc.lights;
+	const c4ptr lights = c4ptr_of(sc.lights);
 	WaveProf wp = {};
 #ifdef RT_PROFILE
 	wp.g = fp.counters;

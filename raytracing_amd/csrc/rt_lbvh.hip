@@ -478,6 +478,8 @@ int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 			set_error("LBVH: the scene has a non-finite vertex; commit it with RT_ACCEL_BRUTE");
 			return RT_ERR_LIMIT;
 		}
+	// (the packet walk addresses its 8 octant copies of the node records, 512 B per node, as a 64-bit base + 32-bit byte offset)
+	if ((unsigned long long)n * 512ull >= 0xffffffffull) { set_error("LBVH: %d triangles need packet records of 4 GiB or more", n); return RT_ERR_LIMIT; }
 	lbvh_free(d);
 	std::vector<int> hoisted;
 	pick_hoisted(s->tris, d.bb_lo, d.bb_hi, hoisted);
