@@ -199,6 +199,13 @@ struct c4ptr {
 		return make_float4(v.x, v.y, v.z, v.w);
 	}
 	__device__ __forceinline__ c4ptr offset_floats(unsigned int f) const { c4ptr r; r.p = p; r.off = off + f * 4u; return r; }
+	// entries i and i+1 (i even: a 32-byte record) in one s_load_dwordx8
+	__device__ __forceinline__ void pair(unsigned int i, float4& a, float4& b) const {
+		typedef float v8f_ __attribute__((ext_vector_type(8)));
+		const v8f_ v = *(const __attribute__((address_space(4))) v8f_*)(p + (off + i * 16u));
+		a = make_float4(v[0], v[1], v[2], v[3]);
+		b = make_float4(v[4], v[5], v[6], v[7]);
+	}
 };
 __device__ __forceinline__ c4ptr c4ptr_of(const void* base) {
 	c4ptr r;
@@ -207,14 +214,20 @@ __device__ __forceinline__ c4ptr c4ptr_of(const void* base) {
 	return r;
 }
 
+// v_max3/v_min3/v_max/v_min without the canonicalising v_max_f32 x, x, x the compiler puts in front of fmaxf/fminf
+// when it cannot prove an operand quiet (the loop-carried limit): one instruction of twelve in every box test.
+// NaN operands are dropped exactly as by fmaxf/fminf (IEEE minNum/maxNum, the instructions' own behaviour).
+__device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float vmax0(float a) { float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(a)); return r; }
+__device__ __forceinline__ float vmin2(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 // Slab test against an octant-ordered box record (near.xyz, far.xyz): for a wave whose rays all
 // point into the same octant the near/far faces are known per axis, so the per-axis min/max of
 // slab_hit falls away: 6 fma + max3/max + min3/min + compare.
 __device__ __forceinline__ bool slab_hit_oct(float4 a, float4 b, vec3 inv, vec3 oi, float lim_hi) {
-	const float tmin = fmaxf(fmaxf(__builtin_fmaf(a.x, inv.x, oi.x), __builtin_fmaf(a.y, inv.y, oi.y)),
-	                         fmaxf(__builtin_fmaf(a.z, inv.z, oi.z), 0.0f));
-	const float tmax = fminf(fminf(__builtin_fmaf(a.w, inv.x, oi.x), __builtin_fmaf(b.x, inv.y, oi.y)),
-	                         fminf(__builtin_fmaf(b.y, inv.z, oi.z), lim_hi));
+	const float tmin = vmax3(__builtin_fmaf(a.x, inv.x, oi.x), __builtin_fmaf(a.y, inv.y, oi.y), vmax0(__builtin_fmaf(a.z, inv.z, oi.z)));
+	const float tmax = vmin3(__builtin_fmaf(a.w, inv.x, oi.x), __builtin_fmaf(b.x, inv.y, oi.y), vmin2(__builtin_fmaf(b.y, inv.z, oi.z), lim_hi));
 	return !(tmin > tmax);
 }
 
@@ -224,7 +237,7 @@ __device__ __forceinline__ Hit cast_ray_pruned(const DevScene& sc, c4ptr tri, in
                                                vec3 inv, vec3 oi, int skip, float lim, bool first_only, WaveProf& wp) {
 	RT_PROF(wp, WP_TRACE);
 	RT_STAMP(wp, 7);        // bounds + slab set-up (since the last outer stamp)
-	const int stride = sc.stride, n = sc.n_tris, n_clusters = sc.n_clusters;
+	const int stride = sc.stride, n_clusters = sc.n_clusters;
 	Hit h;
 	h.t = 1e9f;
 	h.idx = -1;
@@ -239,7 +252,8 @@ __device__ __forceinline__ Hit cast_ray_pruned(const DevScene& sc, c4ptr tri, in
 		int g0, g1;
 		RT_PROF(wp, WP_GROUP);
 		if constexpr (OCT) {
-			const float4 ca = cbox[2 * c], cb = cbox[2 * c + 1];
+			float4 ca, cb;
+			cbox.pair(2 * c, ca, cb);
 			g0 = __float_as_int(cb.z);
 			g1 = g0 + __float_as_int(cb.w);
 			if (__builtin_amdgcn_ballot_w64(slab_hit_oct(ca, cb, inv, oi, lim_hi)) == 0) continue;
@@ -255,7 +269,9 @@ __device__ __forceinline__ Hit cast_ray_pruned(const DevScene& sc, c4ptr tri, in
 			if (!single) {
 				RT_PROF(wp, WP_GROUP);
 				if constexpr (OCT) {
-					if (__builtin_amdgcn_ballot_w64(slab_hit_oct(gbox[2 * g], gbox[2 * g + 1], inv, oi, lim_hi)) == 0) continue;
+					float4 ga, gb;
+					gbox.pair(2 * g, ga, gb);
+					if (__builtin_amdgcn_ballot_w64(slab_hit_oct(ga, gb, inv, oi, lim_hi)) == 0) continue;
 				} else {
 					if (__builtin_amdgcn_ballot_w64(slab_hit(tri[PL_GLO * stride + g], tri[PL_GHI * stride + g], inv, oi, lim_hi)) == 0) continue;
 				}
@@ -264,7 +280,7 @@ __device__ __forceinline__ Hit cast_ray_pruned(const DevScene& sc, c4ptr tri, in
 #pragma unroll
 			for (int k = 0; k < RT_GROUP; k++) {
 				const int i = g * RT_GROUP + k;
-				if (i >= n) break;
+				// (no `i >= n` test: the slots of a last, incomplete group are zero planes — den = 0, t = NaN, never a candidate)
 				RT_PROF(wp, WP_TRI);
 				const vec3 nn = xyz(tri[PL_N * stride + i]);
 				vec3 p1 = make3(0.f, 0.f, 0.f);
