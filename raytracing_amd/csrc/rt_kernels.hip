@@ -128,25 +128,36 @@ __device__ __forceinline__ Hit cast_ray_brute(TriPtr tri, int stride, int n, vec
 //      matters for a triangle that would otherwise be accepted, so both leave the per-triangle path.
 //  (3) For primary rays the numerator dot(p1 - camera, n) of Source.cpp:383 is the same for every
 //      pixel: it is computed once per workgroup (same operations, same bits) and read from LDS.
+// Lane predicates as wave masks.  The conditions of Source.cpp:385-396 are kept as 64-bit masks in SGPRs — one v_cmp
+// per comparison writing the mask, s_and/s_or to combine, s_cmp + branch when no lane is left — instead of per-lane
+// bools: a compound bool handed to ballot() is materialised through a VGPR (v_cndmask + v_cmp_ne per ballot) and
+// `a && b` guards b's arithmetic with an exec save/restore and a branch; with masks the arithmetic runs on every
+// lane (it costs the same issue slot) and only the masks decide.  lane_in() turns a mask back into a lane condition
+// for free (it becomes the select's own condition operand).
+typedef unsigned long long lanemask;
+__device__ __forceinline__ lanemask lanes(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+__device__ __forceinline__ bool lane_in(lanemask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
 // Edge tests and acceptance for ONE triangle whose exact t is known (Source.cpp:389-396).
 template <typename TriPtr>
 __device__ __forceinline__ void accept_triangle(TriPtr tri, int stride, int i, vec3 nn, vec3 p1, vec3 o, vec3 d, float t,
-                                                bool cand, int skip, bool first_only, Hit& h, float& lim, float& lim_hi, WaveProf& wp) {
+                                                lanemask cand, int skip, bool first_only, Hit& h, float& lim, float& lim_hi, WaveProf& wp) {
 	const vec3 I = make3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);   // Source.cpp:389
 	const float4 E0 = tri[PL_E0 * stride + i];
-	const bool c0 = cand && (dot(nn, cross(xyz(E0), I - p1)) > 0.0f);    // Source.cpp:392
-	if (__builtin_amdgcn_ballot_w64(c0) == 0) return;
+	const lanemask c0 = cand & lanes(dot(nn, cross(xyz(E0), I - p1)) > 0.0f);    // Source.cpp:392
+	if (c0 == 0) return;
 	RT_PROF(wp, WP_C0);
 	const float4 P24 = tri[PL_P2 * stride + i];
 	const float4 E1 = tri[PL_E1 * stride + i];
-	const bool c1 = c0 && (dot(nn, cross(xyz(E1), I - xyz(P24))) > 0.0f);   // Source.cpp:393
-	if (__builtin_amdgcn_ballot_w64(c1) == 0) return;
+	const lanemask c1 = c0 & lanes(dot(nn, cross(xyz(E1), I - xyz(P24))) > 0.0f);   // Source.cpp:393
+	if (c1 == 0) return;
 	RT_PROF(wp, WP_C1);
 	const float4 P34 = tri[PL_P3 * stride + i];
 	const float4 E2 = tri[PL_E2 * stride + i];
-	const bool c2 = c1 && (dot(nn, cross(xyz(E2), I - xyz(P34))) > 0.0f);   // Source.cpp:394
-	if (__builtin_amdgcn_ballot_w64(c2) != 0) RT_PROF(wp, WP_ACCEPT);
-	if (c2 && i != skip) {                                                  // Source.cpp:302, 396
+	const lanemask c2 = c1 & lanes(dot(nn, cross(xyz(E2), I - xyz(P34))) > 0.0f) & lanes(i != skip);   // Source.cpp:394, 302
+	if (c2 == 0) return;
+	RT_PROF(wp, WP_ACCEPT);
+	if (lane_in(c2)) {                                                      // Source.cpp:396
 		h.t = t; h.idx = i; h.p = I;
 		lim = first_only ? -1.0f : t;
 		lim_hi = lim + fabsf(lim) * RT_PREFILTER_REL;
@@ -294,13 +305,13 @@ __device__ __forceinline__ Hit cast_ray_pruned(const DevScene& sc, c4ptr tri, in
 				const float den = dot(d, nn);
 				// eps_lo <= num/den <= lim_hi  <=>  num lies between eps_lo*den and lim_hi*den (either order)
 				const float qa = lim_hi * den, qb = eps_lo * den;
-				const bool normal = __builtin_amdgcn_classf(qb, 0x108);         // +-normal: both products are accurate to 2^-24
-				const bool maybe = !normal || (__builtin_amdgcn_fmed3f(num, qa, qb) == num);
-				if (__builtin_amdgcn_ballot_w64(maybe) == 0) continue;
+				// +-normal qb: both products are accurate to 2^-24; anything else goes on to the exact test
+				const lanemask maybe = (lanes(true) & ~lanes(__builtin_amdgcn_classf(qb, 0x108))) | lanes(__builtin_amdgcn_fmed3f(num, qa, qb) == num);
+				if (maybe == 0) continue;
 				RT_PROF(wp, WP_MAYBE);
 				const float t = num / den;                                      // Source.cpp:383
-				const bool cand = maybe && (t > RT_EPS_BELOW) && (t < lim);     // Source.cpp:385, 391
-				if (__builtin_amdgcn_ballot_w64(cand) == 0) continue;
+				const lanemask cand = maybe & lanes(t > RT_EPS_BELOW) & lanes(t < lim);     // Source.cpp:385, 391
+				if (cand == 0) continue;
 				RT_PROF(wp, WP_CAND);
 				if constexpr (PRIMARY) p1 = xyz(tri[PL_P1 * stride + i]);
 				accept_triangle(tri, stride, i, nn, p1, o, d, t, cand, skip, first_only, h, lim, lim_hi, wp);
@@ -330,21 +341,22 @@ __device__ __forceinline__ void packet_leaf(c4ptr T, int i, vec3 o, vec3 d, int 
 	const float den = dot(d, nn);
 	// (no division-free prefilter here: nine of ten triangles whose box a packet reaches are candidates)
 	const float t = num / den;                                              // Source.cpp:383
-	const bool better = (t < lim) || (t == h.t && i < h.idx);               // Source.cpp:391 + index order
-	const bool cand = (t > RT_EPS_BELOW) && better;
-	if constexpr (COUNT) { const bool act = lim >= 0.0f && i != skip; lc.plane += act; lc.point += act && !(t < 0.0f); lc.edge += act && cand; }
-	if (__builtin_amdgcn_ballot_w64(cand) == 0) return;
+	const lanemask better = lanes(t < lim) | (lanes(t == h.t) & lanes(i < h.idx));   // Source.cpp:391 + index order
+	const lanemask cand = lanes(t > RT_EPS_BELOW) & better;
+	if constexpr (COUNT) { const bool act = lim >= 0.0f && i != skip; lc.plane += act; lc.point += act && !(t < 0.0f); lc.edge += act && lane_in(cand); }
+	if (cand == 0) return;
 	RT_PROF(wp, WP_CAND);
 	const float4 P24 = T[2], P34 = T[3], E0 = T[4], E1 = T[5], E2 = T[6];   // the rest of the record in one go
 	const vec3 I = make3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);      // Source.cpp:389
-	const bool c0 = cand && (dot(nn, cross(xyz(E0), I - p1)) > 0.0f);       // Source.cpp:392
-	if constexpr (COUNT) lc.edge += c0 && i != skip;
-	if (__builtin_amdgcn_ballot_w64(c0) == 0) return;
-	const bool c1 = c0 && (dot(nn, cross(xyz(E1), I - xyz(P24))) > 0.0f);   // Source.cpp:393
-	if constexpr (COUNT) lc.edge += c1 && i != skip;
-	if (__builtin_amdgcn_ballot_w64(c1) == 0) return;
-	const bool c2 = c1 && (dot(nn, cross(xyz(E2), I - xyz(P34))) > 0.0f);   // Source.cpp:394
-	if (c2 && i != skip) {                                                  // Source.cpp:302, 396
+	const lanemask c0 = cand & lanes(dot(nn, cross(xyz(E0), I - p1)) > 0.0f);       // Source.cpp:392
+	if constexpr (COUNT) lc.edge += lane_in(c0) && i != skip;
+	if (c0 == 0) return;
+	const lanemask c1 = c0 & lanes(dot(nn, cross(xyz(E1), I - xyz(P24))) > 0.0f);   // Source.cpp:393
+	if constexpr (COUNT) lc.edge += lane_in(c1) && i != skip;
+	if (c1 == 0) return;
+	const lanemask c2 = c1 & lanes(dot(nn, cross(xyz(E2), I - xyz(P34))) > 0.0f) & lanes(i != skip);   // Source.cpp:394, 302
+	if (c2 == 0) return;
+	if (lane_in(c2)) {                                                      // Source.cpp:396
 		h.t = t; h.idx = i; h.p = I;
 		lim = first_only ? -1.0f : t;
 		lim_hi = lim + fabsf(lim) * RT_PREFILTER_REL;
@@ -454,20 +466,20 @@ __device__ __forceinline__ void hoisted_tests(const DevScene& sc, vec3 o, vec3 d
 			const float4 N4 = Tm[0], P14 = Tm[1];
 			const vec3 nn = xyz(N4), p1 = xyz(P14);
 			const float t = dot(p1 - o, nn) / dot(d, nn);                           // Source.cpp:383
-			const bool visit = live && i != skip;                                   // Source.cpp:302
-			const bool cand = visit && (t > RT_EPS_BELOW) && (t < lim);             // Source.cpp:385, 391
-			if constexpr (COUNT) { lc.plane += visit; lc.point += visit && !(t < 0.0f); lc.edge += cand; }
-			if (__builtin_amdgcn_ballot_w64(cand) == 0) continue;
+			const lanemask visit = lanes(live) & lanes(i != skip);                  // Source.cpp:302
+			const lanemask cand = visit & lanes(t > RT_EPS_BELOW) & lanes(t < lim); // Source.cpp:385, 391
+			if constexpr (COUNT) { lc.plane += lane_in(visit); lc.point += lane_in(visit) && !(t < 0.0f); lc.edge += lane_in(cand); }
+			if (cand == 0) continue;
 			const float4 P24 = Tm[2], P34 = Tm[3], E0 = Tm[4], E1 = Tm[5], E2 = Tm[6];
 			const vec3 I = make3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);      // Source.cpp:389
-			const bool c0 = cand && (dot(nn, cross(xyz(E0), I - p1)) > 0.0f);       // Source.cpp:392
-			if constexpr (COUNT) lc.edge += c0;
-			if (__builtin_amdgcn_ballot_w64(c0) == 0) continue;
-			const bool c1 = c0 && (dot(nn, cross(xyz(E1), I - xyz(P24))) > 0.0f);   // Source.cpp:393
-			if constexpr (COUNT) lc.edge += c1;
-			if (__builtin_amdgcn_ballot_w64(c1) == 0) continue;
-			const bool c2 = c1 && (dot(nn, cross(xyz(E2), I - xyz(P34))) > 0.0f);   // Source.cpp:394
-			if (c2) {                                                               // Source.cpp:396
+			const lanemask c0 = cand & lanes(dot(nn, cross(xyz(E0), I - p1)) > 0.0f);       // Source.cpp:392
+			if constexpr (COUNT) lc.edge += lane_in(c0);
+			if (c0 == 0) continue;
+			const lanemask c1 = c0 & lanes(dot(nn, cross(xyz(E1), I - xyz(P24))) > 0.0f);   // Source.cpp:393
+			if constexpr (COUNT) lc.edge += lane_in(c1);
+			if (c1 == 0) continue;
+			const lanemask c2 = c1 & lanes(dot(nn, cross(xyz(E2), I - xyz(P34))) > 0.0f);   // Source.cpp:394
+			if (lane_in(c2)) {                                                      // Source.cpp:396
 				h.t = t; h.idx = i; h.p = I;
 				lim = first_only ? -1.0f : t;
 				lim_hi = lim + fabsf(lim) * RT_PREFILTER_REL;
