@@ -225,21 +225,23 @@ __device__ __forceinline__ c4ptr c4ptr_of(const void* base) {
 	return r;
 }
 
-// v_max3/v_min3/v_max/v_min without the canonicalising v_max_f32 x, x, x the compiler puts in front of fmaxf/fminf
-// when it cannot prove an operand quiet (the loop-carried limit): one instruction of twelve in every box test.
-// NaN operands are dropped exactly as by fmaxf/fminf (IEEE minNum/maxNum, the instructions' own behaviour).
-__device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-__device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-__device__ __forceinline__ float vmax0(float a) { float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(a)); return r; }
-__device__ __forceinline__ float vmin2(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// max(x0, y0, z0, 0) and min(x1, y1, z1, lim) of a slab test as four instructions in ONE asm block: written with
+// fmaxf/fminf the compiler puts a canonicalising v_max_f32 x, x, x in front of every use of an operand it cannot prove
+// quiet (the loop-carried limit) — one instruction of twelve in every box test — and around separate asm statements it
+// pads with s_nops.  NaN operands are dropped exactly as by fmaxf/fminf (minNum/maxNum, the instructions' own behaviour).
+__device__ __forceinline__ bool slab_interval_hit(float x0, float y0, float z0, float x1, float y1, float z1, float lim) {
+	float tmin, tmax;
+	asm("v_max_f32 %0, 0, %4\n\tv_max3_f32 %0, %2, %3, %0\n\tv_min_f32 %1, %7, %8\n\tv_min3_f32 %1, %5, %6, %1"
+	    : "=&v"(tmin), "=&v"(tmax) : "v"(x0), "v"(y0), "v"(z0), "v"(x1), "v"(y1), "v"(z1), "v"(lim));
+	return !(tmin > tmax);
+}
 
 // Slab test against an octant-ordered box record (near.xyz, far.xyz): for a wave whose rays all
 // point into the same octant the near/far faces are known per axis, so the per-axis min/max of
 // slab_hit falls away: 6 fma + max3/max + min3/min + compare.
 __device__ __forceinline__ bool slab_hit_oct(float4 a, float4 b, vec3 inv, vec3 oi, float lim_hi) {
-	const float tmin = vmax3(__builtin_fmaf(a.x, inv.x, oi.x), __builtin_fmaf(a.y, inv.y, oi.y), vmax0(__builtin_fmaf(a.z, inv.z, oi.z)));
-	const float tmax = vmin3(__builtin_fmaf(a.w, inv.x, oi.x), __builtin_fmaf(b.x, inv.y, oi.y), vmin2(__builtin_fmaf(b.y, inv.z, oi.z), lim_hi));
-	return !(tmin > tmax);
+	return slab_interval_hit(__builtin_fmaf(a.x, inv.x, oi.x), __builtin_fmaf(a.y, inv.y, oi.y), __builtin_fmaf(a.z, inv.z, oi.z),
+	                         __builtin_fmaf(a.w, inv.x, oi.x), __builtin_fmaf(b.x, inv.y, oi.y), __builtin_fmaf(b.y, inv.z, oi.z), lim_hi);
 }
 
 // OCT: every live ray of the wave points into octant `oct` (bit k = component k negative).

@@ -134,9 +134,10 @@ __device__ __forceinline__ Hit cast_ray_lbvh(const DevScene& sc, int* lds_stack,
 		}
 #endif
 		if (inner) {
-			const uint4* nd = sc.bvh4 + (size_t)node * 4;
-			const uint4 w0 = nd[0], w1 = nd[1], w2 = nd[2];
-			const uint2 w3 = *(const uint2*)(nd + 3);
+			// (uniform base + 32-bit byte offset: the load's own addressing form, no 64-bit address arithmetic per lane)
+			const char* nd = (const char*)sc.bvh4 + (unsigned int)node * 64u;
+			const uint4 w0 = *(const uint4*)nd, w1 = *(const uint4*)(nd + 16), w2 = *(const uint4*)(nd + 32);
+			const uint2 w3 = *(const uint2*)(nd + 48);
 			// per axis: t(q) = (p + q * 2^e) * inv + oi = q * A + B
 			const float Ax = __uint_as_float((w0.w & 0xffu) << 23) * s.inv.x, Bx = __builtin_fmaf(__uint_as_float(w0.x), s.inv.x, s.oi.x);
 			const float Ay = __uint_as_float(((w0.w >> 8) & 0xffu) << 23) * s.inv.y, By = __builtin_fmaf(__uint_as_float(w0.y), s.inv.y, s.oi.y);
@@ -149,12 +150,13 @@ __device__ __forceinline__ Hit cast_ray_lbvh(const DevScene& sc, int* lds_stack,
 			const unsigned int ny = Ay >= 0.0f ? w2.y : w3.x, fy = Ay >= 0.0f ? w3.x : w2.y;
 			const unsigned int nz = Az >= 0.0f ? w2.z : w3.y, fz = Az >= 0.0f ? w3.y : w2.z;
 #define RT_QB(word, c) ((float)(((word) >> (8 * (c))) & 0xffu))      /* v_cvt_f32_ubyteN */
+			const float lim_q = __builtin_canonicalizef(lim_hi);           // once per node instead of once per child (fminf quiets its operands)
 #pragma unroll
 			for (int c = 0; c < 4; c++) {
 				const float tmin = fmaxf(fmaxf(__builtin_fmaf(RT_QB(nx, c), Ax, Bx), __builtin_fmaf(RT_QB(ny, c), Ay, By)),
 				                         fmaxf(__builtin_fmaf(RT_QB(nz, c), Az, Bz), 0.0f));
 				const float tmax = fminf(fminf(__builtin_fmaf(RT_QB(fx, c), Ax, Bx), __builtin_fmaf(RT_QB(fy, c), Ay, By)),
-				                         fminf(__builtin_fmaf(RT_QB(fz, c), Az, Bz), lim_hi));
+				                         fminf(__builtin_fmaf(RT_QB(fz, c), Az, Bz), lim_q));
 				const bool present = ref[c] != RT_BVH4_EMPTY;
 				key[c] = (present && !(tmin > tmax)) ? tmin : inf;            // A, B are finite: no NaN here
 				if (COUNT) lc.box += present;
@@ -196,30 +198,34 @@ __device__ __forceinline__ Hit cast_ray_lbvh(const DevScene& sc, int* lds_stack,
 #endif
 		if (leaf_trip && has) {
 			const int i = ~pend;
-			const float4* T = sc.tri_aos + (size_t)i * 8;
+			const float4* T = (const float4*)((const char*)sc.tri_aos + (unsigned int)i * 128u);
 			const float4 N4 = T[0], P14 = T[1], P24 = T[2], P34 = T[3], E0 = T[4], E1 = T[5], E2 = T[6];
 			const vec3 nn = xyz(N4), p1 = xyz(P14);
 			const float t = dot(p1 - o, nn) / dot(d, nn);                                 // Source.cpp:383
-			const bool visit = (i != skip);                                               // Source.cpp:302
-			const bool better = (t < lim) || (t == h.t && i < h.idx);                     // Source.cpp:391 + index order
-			const bool cand = visit && (t > RT_EPS_BELOW) && better;                      // Source.cpp:385, 391
-			if (COUNT) { lc.plane += visit; lc.point += visit && !(t < 0.0f); lc.edge += cand; }
-			bool found = false;
-			if (cand) {
+			// lane predicates as wave masks (rt_kernels.hip lanemask); the lanes of this leaf trip only
+			const lanemask visit = lanes(i != skip);                                      // Source.cpp:302
+			const lanemask better = lanes(t < lim) | (lanes(t == h.t) & lanes(i < h.idx)); // Source.cpp:391 + index order
+			const lanemask cand = visit & lanes(t > RT_EPS_BELOW) & better;               // Source.cpp:385, 391
+			if (COUNT) { lc.plane += lane_in(visit); lc.point += lane_in(visit) && !(t < 0.0f); lc.edge += lane_in(cand); }
+			lanemask found_m = 0;
+			if (cand != 0) {
 				const vec3 I = make3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);        // Source.cpp:389
-				if (dot(nn, cross(xyz(E0), I - p1)) > 0.0f) {                             // Source.cpp:392
-					if (COUNT) lc.edge++;
-					if (dot(nn, cross(xyz(E1), I - xyz(P24))) > 0.0f) {                   // Source.cpp:393
-						if (COUNT) lc.edge++;
-						if (dot(nn, cross(xyz(E2), I - xyz(P34))) > 0.0f) {               // Source.cpp:394
+				const lanemask c0 = cand & lanes(dot(nn, cross(xyz(E0), I - p1)) > 0.0f); // Source.cpp:392
+				if (COUNT) lc.edge += lane_in(c0);
+				if (c0 != 0) {
+					const lanemask c1 = c0 & lanes(dot(nn, cross(xyz(E1), I - xyz(P24))) > 0.0f);   // Source.cpp:393
+					if (COUNT) lc.edge += lane_in(c1);
+					if (c1 != 0) {
+						found_m = c1 & lanes(dot(nn, cross(xyz(E2), I - xyz(P34))) > 0.0f);         // Source.cpp:394
+						if (lane_in(found_m)) {
 							h.t = t; h.idx = i; h.p = I;                                  // Source.cpp:396
 							lim = t;
 							lim_hi = lim + fabsf(lim) * RT_PREFILTER_REL;
-							found = true;
 						}
 					}
 				}
 			}
+			const bool found = lane_in(found_m);
 			pend = SENT;
 			if (found && shadow) { node = SENT; sp = 0; }                                 // a shadow ray only asks whether a hit with t <= dist exists
 			else if (node < 0) { pend = node; node = pop(); }
