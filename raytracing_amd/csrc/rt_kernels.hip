@@ -611,6 +611,21 @@ __device__ __forceinline__ vec3 primary_dir(int x, int y, const FrameParams& fp,
 	return r;
 }
 
+// primary_dir for a launch whose u, v are division-free (FrameParams::uv_fast) — the branch-free body of the above
+__device__ __forceinline__ vec3 primary_dir_plain(int x, int y, const FrameParams& fp, int frame) {
+	const float hf = (float)fp.height, wf = (float)fp.width;
+	const float nv = (float)y - hf * 0.5f, nu = (float)x - wf * 0.5f;
+	const float qv = nv * fp.rcp_h, qu = nu * fp.rcp_w;
+	const float v = __builtin_fmaf(__builtin_fmaf(-qv, hf, nv), fp.rcp_h, qv);
+	const float u = __builtin_fmaf(__builtin_fmaf(-qu, wf, nu), fp.rcp_w, qu);
+	const float* m = fp.pose[frame];
+	vec3 r;
+	r.x = (m[3] * u + m[6] * v) + m[9];
+	r.y = (m[4] * u + m[7] * v) + m[10];
+	r.z = (m[5] * u + m[8] * v) + m[11];
+	return r;
+}
+
 template <bool COUNT>
 __device__ __forceinline__ void flush_counters(unsigned long long* g, const unsigned int (&v)[CTR_N]) {
 	if (!COUNT || g == nullptr) return;
@@ -1043,7 +1058,10 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 #ifndef RT_LOCKSTEP_TILES
 #define RT_LOCKSTEP_TILES 4
 #endif
-template <int ACCEL>
+// PLAIN: a whole frame (no row tiles) whose u, v are division-free — the launcher's common case, compiled without the
+// row mapping and the slow forms of Source.cpp:534-535, whose wave-uniform conditions otherwise sit in spilled SGPRs
+// and are re-read for every tile.  Instantiated for packets only (launch_render).
+template <int ACCEL, bool PLAIN>
 __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL == 3 ? RT_MIN_WAVES_PACKET : RT_MIN_WAVES)) render_lockstep_kernel(DevScene sc, FrameParams fp, int tiles_per_wave) {
 	extern __shared__ float4 s_tri[];
 	float* s_num0 = (float*)s_tri;
@@ -1086,7 +1104,9 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 		const bool inside = (x < fp.width) && (ly < fp.local_rows);
 		if (++tx == tiles_x) { tx = 0; ty++; }
 		// ---- primary ray (Source.cpp:534-548)
-		const vec3 d = primary_dir(x, global_row(ly, fp), fp, frame);
+		vec3 d;
+		if constexpr (PLAIN) d = primary_dir_plain(x, ly, fp, frame);
+		else d = primary_dir(x, global_row(ly, fp), fp, frame);
 		const Hit h = trace_kind<ACCEL, RAY_PRIMARY>(sc, s_num0, cam, d, -1, inside, 0.f, wp);
 		const bool hit = inside && h.idx >= 0;
 		float4 A = make_float4(0.f, 0.f, 0.f, 0.f);                          // colour, shininess of the triangle to be lit
@@ -1311,22 +1331,26 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 			grid = dim3((unsigned)(band_blocks * 8 * n_frames));
 		}
 	}
+	// render_lockstep_kernel<3, PLAIN>: measured +1.5 % for packets; the brute-force and per-lane instances got 2-3 % SLOWER
+	// with it (register allocation), so they keep the general form
+	const bool plain = fp.uv_fast && fp.tile_stride == 1 && fp.tile_first == 0;
 	if (accel == RT_ACCEL_LBVH) {
 		const size_t lds = (size_t)RT_STACK_LDS * RT_STACK_PITCH * sizeof(int);   // [entry][lane]
 		if (count && sc_sel.skip_count > 0) hipLaunchKernelGGL((render_kernel<3, true>), grid, block, 0, stream, sc_sel, fp, tpw);   // the traversal the frame really gets
 		else if (count) hipLaunchKernelGGL((render_kernel<2, true>), grid, block, lds, stream, sc_sel, fp, tpw);
-		else if (sc_sel.skip_count > 0 && lockstep) hipLaunchKernelGGL((render_lockstep_kernel<3>), grid, block, 0, stream, sc_sel, fp, tpw);
+		else if (sc_sel.skip_count > 0 && lockstep && plain) hipLaunchKernelGGL((render_lockstep_kernel<3, true>), grid, block, 0, stream, sc_sel, fp, tpw);
+		else if (sc_sel.skip_count > 0 && lockstep) hipLaunchKernelGGL((render_lockstep_kernel<3, false>), grid, block, 0, stream, sc_sel, fp, tpw);
 		else if (sc_sel.skip_count > 0) hipLaunchKernelGGL((render_kernel<3, false>), grid, block, 0, stream, sc_sel, fp, tpw);
-		else if (lockstep) hipLaunchKernelGGL((render_lockstep_kernel<2>), grid, block, lds, stream, sc_sel, fp, tpw);
+		else if (lockstep) hipLaunchKernelGGL((render_lockstep_kernel<2, false>), grid, block, lds, stream, sc_sel, fp, tpw);
 		else hipLaunchKernelGGL((render_kernel<2, false>), grid, block, lds, stream, sc_sel, fp, tpw);
 	} else if (sc.n_tris <= RT_LDS_MAX_TRIS) {
 		const size_t lds = (size_t)lds_stride_of(sc.n_tris) * sizeof(float);
 		if (count) hipLaunchKernelGGL((render_kernel<0, true>), grid, block, lds, stream, sc_sel, fp, tpw);
-		else if (lockstep) hipLaunchKernelGGL((render_lockstep_kernel<0>), grid, block, lds, stream, sc_sel, fp, tpw);
+		else if (lockstep) hipLaunchKernelGGL((render_lockstep_kernel<0, false>), grid, block, lds, stream, sc_sel, fp, tpw);
 		else hipLaunchKernelGGL((render_kernel<0, false>), grid, block, lds, stream, sc_sel, fp, tpw);
 	} else {
 		if (count) hipLaunchKernelGGL((render_kernel<1, true>), grid, block, 0, stream, sc_sel, fp, tpw);
-		else if (lockstep) hipLaunchKernelGGL((render_lockstep_kernel<1>), grid, block, 0, stream, sc_sel, fp, tpw);
+		else if (lockstep) hipLaunchKernelGGL((render_lockstep_kernel<1, false>), grid, block, 0, stream, sc_sel, fp, tpw);
 		else hipLaunchKernelGGL((render_kernel<1, false>), grid, block, 0, stream, sc_sel, fp, tpw);
 	}
 	hipError_t e = hipGetLastError();
