@@ -259,14 +259,15 @@ __device__ __forceinline__ Hit cast_ray_pruned(const DevScene& sc, c4ptr tri, in
 	const float eps_lo = RT_EPS_BELOW * (1.0f - RT_PREFILTER_REL);
 	const c4ptr cbox = tri.offset_floats((unsigned int)sc.oct_clusters + (unsigned int)oct * (unsigned int)sc.oct_cluster_pitch * 8u);
 	const c4ptr gbox = tri.offset_floats((unsigned int)sc.oct_groups + (unsigned int)oct * (unsigned int)sc.oct_group_pitch * 8u);
-	for (int c = 0; c < n_clusters; c++) {
+	c4ptr crec = cbox;                                   // (running byte offsets: one scalar add per record)
+	for (int c = 0; c < n_clusters; c++, crec.off += 32u) {
 		// one record per cluster: its box and its run of groups.  A cluster of one group has that
 		// group's box, so its test stands for the group's and the group record is never fetched.
 		int g0, g1;
 		RT_PROF(wp, WP_GROUP);
 		if constexpr (OCT) {
 			float4 ca, cb;
-			cbox.pair(2 * c, ca, cb);
+			crec.pair(0, ca, cb);
 			g0 = __float_as_int(cb.z);
 			g1 = g0 + __float_as_int(cb.w);
 			if (__builtin_amdgcn_ballot_w64(slab_hit_oct(ca, cb, inv, oi, lim_hi)) == 0) continue;
@@ -278,12 +279,13 @@ __device__ __forceinline__ Hit cast_ray_pruned(const DevScene& sc, c4ptr tri, in
 			if (__builtin_amdgcn_ballot_w64(slab_hit(clo, chi, inv, oi, lim_hi)) == 0) continue;
 		}
 		const bool single = g1 - g0 == 1;
-		for (int g = g0; g < g1; g++) {
+		c4ptr grec = gbox.offset_floats((unsigned int)g0 * 8u);
+		for (int g = g0; g < g1; g++, grec.off += 32u) {
 			if (!single) {
 				RT_PROF(wp, WP_GROUP);
 				if constexpr (OCT) {
 					float4 ga, gb;
-					gbox.pair(2 * g, ga, gb);
+					grec.pair(0, ga, gb);
 					if (__builtin_amdgcn_ballot_w64(slab_hit_oct(ga, gb, inv, oi, lim_hi)) == 0) continue;
 				} else {
 					if (__builtin_amdgcn_ballot_w64(slab_hit(tri[PL_GLO * stride + g], tri[PL_GHI * stride + g], inv, oi, lim_hi)) == 0) continue;
