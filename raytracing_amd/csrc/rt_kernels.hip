@@ -210,6 +210,15 @@ struct c4ptr {
 		return make_float4(v.x, v.y, v.z, v.w);
 	}
 	__device__ __forceinline__ c4ptr offset_floats(unsigned int f) const { c4ptr r; r.p = p; r.off = off + f * 4u; return r; }
+	// entries i .. i+3 (a 64-byte record) in one s_load_dwordx16
+	__device__ __forceinline__ void quad(unsigned int i, float4& a, float4& b, float4& c, float4& d) const {
+		typedef float v16f_ __attribute__((ext_vector_type(16)));
+		const v16f_ v = *(const __attribute__((address_space(4))) v16f_*)(p + (off + i * 16u));
+		a = make_float4(v[0], v[1], v[2], v[3]);
+		b = make_float4(v[4], v[5], v[6], v[7]);
+		c = make_float4(v[8], v[9], v[10], v[11]);
+		d = make_float4(v[12], v[13], v[14], v[15]);
+	}
 	// entries i and i+1 (i even: a 32-byte record) in one s_load_dwordx8
 	__device__ __forceinline__ void pair(unsigned int i, float4& a, float4& b) const {
 		typedef float v8f_ __attribute__((ext_vector_type(8)));
@@ -350,7 +359,7 @@ __device__ __forceinline__ void packet_leaf(c4ptr T, int i, vec3 o, vec3 d, int 
 	if constexpr (COUNT) { const bool act = lim >= 0.0f && i != skip; lc.plane += act; lc.point += act && !(t < 0.0f); lc.edge += act && lane_in(cand); }
 	if (cand == 0) return;
 	RT_PROF(wp, WP_CAND);
-	const float4 P24 = T[2], P34 = T[3], E0 = T[4], E1 = T[5], E2 = T[6];   // the rest of the record in one go
+	const float4 P24 = T[2], P34 = T[3], E0 = T[4], E1 = T[5], E2 = T[6];   // the rest of the record in one go (wider loads were measured slower: SGPR pressure)
 	const vec3 I = make3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);      // Source.cpp:389
 	const lanemask c0 = cand & lanes(dot(nn, cross(xyz(E0), I - p1)) > 0.0f);       // Source.cpp:392
 	if constexpr (COUNT) lc.edge += lane_in(c0) && i != skip;
@@ -410,8 +419,8 @@ __device__ __forceinline__ Hit cast_ray_packet(const DevScene& sc, int oct, vec3
 	int sp = 0;
 	int node = 0;
 	for (;;) {
-		const c4ptr R = rec.offset_floats((unsigned int)node * 16u);
-		const float4 q0 = R[0], q1 = R[1], q2 = R[2], q3 = R[3];
+		float4 q0, q1, q2, q3;
+		rec.quad((unsigned int)node * 4u, q0, q1, q2, q3);
 		const int refA = __float_as_int(q1.z), refB = __float_as_int(q1.w);
 		RT_PROF(wp, WP_GROUP);
 		if constexpr (COUNT) lc.box += lim >= 0.0f;
