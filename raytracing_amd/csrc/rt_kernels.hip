@@ -744,9 +744,28 @@ __device__ __forceinline__ Hit trace(const DevScene& sc, const float4* lds_tri, 
 // castRay by brute force for ONE kind of ray (the lockstep kernel below knows at every call site whether
 // its rays are primary, bounce or shadow rays, so each site carries only the variants it can need).
 enum { RAY_PRIMARY = 0, RAY_BOUNCE = 1, RAY_SHADOW = 2 };
+
+// The scene constants a trace needs (box, guard, offsets, counts: ~17 SGPRs) RE-READ from the kernel arguments —
+// a few scalar loads per trace — instead of living in SGPRs for the whole kernel, where the register allocator
+// spills them to VGPR lanes and every use costs a v_readlane (a vector-ALU slot).  DevScene is the first argument
+// of every kernel that gets here (so it sits at offset 0 of the kernel-argument segment); the empty asm keeps the
+// loads from being hoisted back out of the tile loop; only the words a trace uses survive as loads.
+__device__ __forceinline__ DevScene scene_from_kernel_args(const DevScene& sc_arg) {
+	DevScene sc = sc_arg;
+#if defined(__HIP_DEVICE_COMPILE__)
+	static_assert(sizeof(DevScene) % 4 == 0, "copied word by word");
+	const __attribute__((address_space(4))) unsigned int* w = (const __attribute__((address_space(4))) unsigned int*)__builtin_amdgcn_kernarg_segment_ptr();
+	asm volatile("" : "+s"(w));
+	unsigned int* dst = (unsigned int*)&sc;
+#pragma unroll
+	for (unsigned int k = 0; k < sizeof(DevScene) / 4; k++) dst[k] = w[k];
+#endif
+	return sc;
+}
 template <int ACCEL, int KIND>
-__device__ __forceinline__ Hit trace_brute(const DevScene& sc, const float* lds_num0, vec3 o, vec3 d, int skip, bool live, float dist, WaveProf& wp) {
+__device__ __forceinline__ Hit trace_brute(const DevScene& sc_arg, const float* lds_num0, vec3 o, vec3 d, int skip, bool live, float dist, WaveProf& wp) {
 	static_assert(ACCEL == 0 || ACCEL == 1, "brute force only");
+	const DevScene sc = scene_from_kernel_args(sc_arg);
 	// (the comments of trace<> above apply word for word: clamped direction, exit bound, far_guard, octant)
 	const vec3 ds = make3(fabsf(d.x) < 1e-30f ? 1e-30f : d.x, fabsf(d.y) < 1e-30f ? 1e-30f : d.y, fabsf(d.z) < 1e-30f ? 1e-30f : d.z);
 	const bool near = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) < sc.far_guard;
@@ -777,7 +796,8 @@ __device__ __forceinline__ Hit trace_brute(const DevScene& sc, const float* lds_
 // castRay over the LBVH by packets for ONE kind of ray (lockstep kernel): one walk per direction octant
 // present among the live lanes (one pass for almost every wave).  Same set-up as trace<3>.
 template <int KIND>
-__device__ __forceinline__ Hit trace_packet(const DevScene& sc, vec3 o, vec3 d, int skip, bool live, float dist, WaveProf& wp) {
+__device__ __forceinline__ Hit trace_packet(const DevScene& sc_arg, vec3 o, vec3 d, int skip, bool live, float dist, WaveProf& wp) {
+	const DevScene sc = scene_from_kernel_args(sc_arg);
 	const vec3 ds = make3(fabsf(d.x) < 1e-30f ? 1e-30f : d.x, fabsf(d.y) < 1e-30f ? 1e-30f : d.y, fabsf(d.z) < 1e-30f ? 1e-30f : d.z);
 	const bool near = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) < sc.far_guard;   // false for NaN too
 	vec3 inv = make3(__builtin_amdgcn_rcpf(ds.x), __builtin_amdgcn_rcpf(ds.y), __builtin_amdgcn_rcpf(ds.z));
