@@ -1318,11 +1318,12 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 	const long long tiles = (long long)((fp.width + RT_TILE_W - 1) / RT_TILE_W) * ((fp.local_rows + RT_TILE_H - 1) / RT_TILE_H);
 	if (tiles * 64 > 0xf0000000LL) { set_error("rt_render: %dx%d needs more than 2^32 work items", fp.width, fp.local_rows); return RT_ERR_LIMIT; }
 	// (the lockstep kernel walks its tiles one after the other, so longer runs only amortise the per-workgroup
-	// set-up; measured best at 4 for brute force: 2 and 8 are 1-4 % slower)
+	// set-up; brute force, measured (scripts/tiles_sweep.sh), us/frame at 1 | 2 | 4 | 8 | 16 tiles: room 800x800 x32 frames
+	// 14.1 | 13.5 | 13.3 | 14.1, 1600x1600 - | - | 47.4 | 45.2, mirrors 3840x2160 255 | 242 | 236 | 233 | 239, room 7680x4320 653 | 613 | 585 | 567 | 573)
 	// AUTO is the lockstep form: measured faster than, or equal to, the state machine on every scene tried, up to
 	// depth 16 and with bounce depths that diverge inside a tile
 	const bool lockstep = !count && sc.kernel_kind != RT_KERNEL_STATE_MACHINE;
-	int tpw = fp.tiles_per_wave > 0 ? fp.tiles_per_wave : (lockstep && accel != RT_ACCEL_LBVH ? (tiles * n_frames >= 16 * 8192 ? RT_LOCKSTEP_TILES : (tiles * n_frames >= 4 * 8192 ? 2 : 1))
+	int tpw = fp.tiles_per_wave > 0 ? fp.tiles_per_wave : (lockstep && accel != RT_ACCEL_LBVH ? (tiles * n_frames >= 128 * 8192 ? 2 * RT_LOCKSTEP_TILES : (tiles * n_frames >= 16 * 8192 ? RT_LOCKSTEP_TILES : (tiles * n_frames >= 4 * 8192 ? 2 : 1)))
 	                                                                                           : pick_tiles_per_wave(accel, tiles * n_frames));
 	const long long waves = (tiles + tpw - 1) / tpw;
 #ifdef RT_EXPERIMENT
