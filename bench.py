@@ -425,7 +425,7 @@ def run_tile_mode(args, api, torch, dist, rank, world, dev, on_gpu, name):
             done += ex.drain()
             return done
 
-        run([frames[s % len(frames)] for s in range(warmup)], False)
+        run([frames[s % len(frames)] for s in range(max(1, warmup))], False)    # (at least one untimed exchange: the first one sets up the communicator)
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
