@@ -1325,6 +1325,9 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 	const bool lockstep = !count && sc.kernel_kind != RT_KERNEL_STATE_MACHINE;
 	int tpw = fp.tiles_per_wave > 0 ? fp.tiles_per_wave : (lockstep && accel != RT_ACCEL_LBVH ? (tiles * n_frames >= 128 * 8192 ? 2 * RT_LOCKSTEP_TILES : (tiles * n_frames >= 16 * 8192 ? RT_LOCKSTEP_TILES : (tiles * n_frames >= 4 * 8192 ? 2 : 1)))
 	                                                                                           : pick_tiles_per_wave(accel, tiles * n_frames));
+	// (tree kernels: one tile, except frames of 400k tiles and more — 102k triangles, measured 1 | 2 tiles: 3840x2160 214.6 | 222.7 us,
+	// 7680x4320 799 | 773)
+	if (fp.tiles_per_wave <= 0 && lockstep && accel == RT_ACCEL_LBVH && tiles >= 400000) tpw = 2;
 	const long long waves = (tiles + tpw - 1) / tpw;
 #ifdef RT_EXPERIMENT
 	static const int env_block = [] { const char* e = getenv("RT355_BLOCK_THREADS"); int v = e ? atoi(e) : 0; return (v == 64 || v == 128 || v == 256) ? v : 0; }();
