@@ -54,6 +54,17 @@ extern "C" {
  * (8K: 133 MB instead of 398 MB).  The `float*` output arguments then point at width*height 4-byte
  * pixels, and frame_stride_floats counts 4-byte pixels. */
 #define RT_OUT_RGBA8 0x100
+/* Shading bit, accepted wherever RT_OUT_RGBA8 is: the colour arithmetic of the reference's OTHER renderer, the GL
+ * compute shader its `GPU` switch selects (Compute.shader:140-219, 224-345, host side Src:1168-1243), for cross-checking
+ * frames against a machine that runs that shader.  Same primary rays and the same castRay; what differs:
+ * no reflections — every hit is lit as matte, shininess is ignored (Compute.shader:257-330); per unshadowed light the
+ * SCALAR (1.0 / (dist*dist) * intensity) / 255.0 is summed in binary32 (Compute.shader:214; Src:488 divides in binary64),
+ * then colour = (sum * triangle colour) / 255.0 (Compute.shader:330); nothing is clamped to 1 (the shader stores into an
+ * rgba32f image).  Evaluated here in IEEE binary32 in the shader's written order with glm's normalize; GLSL leaves the
+ * precision of /, sqrt and normalize to the driver, so a real GL machine may differ in the last bits: this mode is
+ * "parity unpinned" (no GL here to run the shader), checked against the oracle's restatement of the shader only.
+ * max_bounces is ignored.  Runs the state-machine kernel: a checking mode, not a fast path. */
+#define RT_SHADE_GLSL 0x200
 
 /* One triangle record as the reference stores it (Src:31-43), 28 floats:
  * p[3] n[3] p1[3] p2[3] p3[3] edge0[3] edge1[3] edge2[3] color[3] shininess */

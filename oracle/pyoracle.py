@@ -61,6 +61,7 @@ def lib():
                                       C.c_int, C.c_int, C.c_int, _fp, C.POINTER(Counters)]
         L.orc_render_mt.argtypes = [_fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.c_int,
                                     C.c_int, _fp, C.POINTER(Counters)]
+        L.orc_render_glsl.argtypes = [_fp, C.c_int, _fp, C.c_int, _fp, _fp, C.c_int, C.c_int, _fp]
         L.orc_quantize.argtypes = [_fp, C.c_size_t, C.POINTER(C.c_uint8)]
         L.orc_flops.argtypes = [C.POINTER(Counters)]
         L.orc_flops.restype = C.c_double
@@ -154,6 +155,15 @@ def render(tris, lights, cam_pos, trans16, width, height, depth=1, threads=1,
     else:
         lib().orc_render(_p(tris), n, _p(lights), nl, _p(cam), _p(tr), width, height, depth, _p(out), cp)
     return (out, ctr) if counters else out
+
+
+def render_glsl(tris, lights, cam_pos, trans16, width, height):
+    """Full frame (H,W,3) float32 by the restated compute shader (Compute.shader:140-345; parity unpinned)."""
+    tris, lights = _f32(tris), _f32(lights)
+    cam, tr = _f32(cam_pos), _f32(trans16)
+    out = np.zeros((height, width, 3), dtype=np.float32)
+    lib().orc_render_glsl(_p(tris), tris.shape[0], _p(lights), lights.shape[0], _p(cam), _p(tr), width, height, _p(out))
+    return out
 
 
 def render_desc(desc, threads=1, counters=False):

@@ -428,6 +428,76 @@ void orc_render_mt(const float* tris28, int n_tris, const float* lights4, int n_
 	free(th);
 }
 
+/* ---- the reference's OTHER renderer: RayTracing/src/Compute.shader ("CS"), the GL compute shader ----
+ * PARITY UNPINNED: there is no GL in this image to run the shader, and GLSL leaves the precision of /, sqrt,
+ * normalize and the summation order of mat4 * vec4 to the driver.  This restates the shader's written
+ * operation order in IEEE binary32 with glm's orders for the built-ins (dot3, cross3, normalize3, m4mulv
+ * above); it is what RT_SHADE_GLSL is checked against, nothing more. */
+
+/* CS:140-175 castRay: the loop of Src:301-402 with an index for the skipped triangle and the literal .00001
+ * as a binary32 constant (same decisions: for a binary32 t, t > 1e-5f  <=>  (double)t > 0.00001). */
+static payload glsl_cast_ray(const float* tris, int n, v3 orgin, v3 dir, int index) {
+	payload closest = { { 0, 0, 0 }, 1e9f, -1, 0 };
+	for (int i = 0; i < n; i++) {
+		if (i == index) continue;                                          /* CS:144 */
+		const float* T = tris + (size_t)i * ORC_TRI_FLOATS;
+		v3 nn = ld3(T + 3), p1 = ld3(T + 6), p2 = ld3(T + 9), p3 = ld3(T + 12);
+		float t = dot3(v3sub(p1, orgin), nn) / dot3(dir, nn);              /* CS:152 */
+		if (t < 0) continue;                                               /* CS:153 */
+		v3 I = { orgin.x + t * dir.x, orgin.y + t * dir.y, orgin.z + t * dir.z };   /* CS:157 */
+		if (t < closest.distance && t > .00001f) {                         /* CS:159 */
+			if (dot3(nn, cross3(ld3(T + 15), v3sub(I, p1))) > 0.0f &&      /* CS:161-163 */
+			    dot3(nn, cross3(ld3(T + 18), v3sub(I, p2))) > 0.0f &&
+			    dot3(nn, cross3(ld3(T + 21), v3sub(I, p3))) > 0.0f) {
+				closest.point = I;
+				closest.distance = t;
+				closest.cur = i;
+				closest.didHit = 1;
+			}
+		}
+	}
+	return closest;
+}
+
+/* CS:224-345 main() per pixel, CS:181-219 processLighting.  out_rgb as orc_render (the shader's alpha = 1 is
+ * dropped); nothing is clamped (imageStore into rgba32f, CS:7, 345). */
+void orc_render_glsl(const float* tris28, int n_tris, const float* lights4, int n_lights,
+                     const float cam_pos[3], const float trans16[16], int width, int height, float* out_rgb) {
+	m4 trans;
+	memcpy(&trans, trans16, sizeof trans);
+	v3 cam = ld3(cam_pos);
+	for (int y = 0; y < height; y++)
+		for (int x = 0; x < width; x++) {
+			float v = ((float)y - (float)height / 2.0f) / (float)height;   /* CS:235 (GLSL: all binary32) */
+			float u = ((float)x - (float)width / 2.0f) / (float)width;     /* CS:236 */
+			v4 in = { u, v, .5f, 1.0f };
+			v4 pixel2 = m4mulv(trans, in);                                 /* CS:239 */
+			v3 dir = { pixel2.x, pixel2.y, pixel2.z };
+			payload hit = glsl_cast_ray(tris28, n_tris, cam, dir, -1);     /* CS:251 */
+			v3 color = { 0, 0, 0 };                                        /* CS:253 */
+			if (hit.didHit) {                                              /* CS:257 */
+				float result = 0.0f;                                       /* CS:182: vec3 of three equal scalars */
+				for (int i = 0; i < n_lights; i++) {                       /* CS:188 */
+					v3 ray = v3sub(ld3(lights4 + 4 * i), hit.point);       /* CS:193 */
+					v3 lightDir = normalize3(ray);                         /* CS:196 */
+					payload hit2 = glsl_cast_ray(tris28, n_tris, hit.point, lightDir, hit.cur);   /* CS:197 */
+					float dist = sqrtf(ray.x * ray.x + ray.y * ray.y + ray.z * ray.z);            /* CS:177-179, 198 */
+					if (!hit2.didHit || hit2.distance > dist) {            /* CS:203 */
+						float dist_ = dist;                                /* CS:213 */
+						result = result + 1.0f / (dist_ * dist_) * lights4[4 * i + 3] / 255.0f;   /* CS:214 */
+					}
+				}
+				const float* HC = tris28 + (size_t)hit.cur * ORC_TRI_FLOATS + 24;
+				float lighting = 0.0f + result;                            /* CS:330: indirect (CS:272, 0) + direct */
+				color.x = lighting * HC[0] / 255.0f;
+				color.y = lighting * HC[1] / 255.0f;
+				color.z = lighting * HC[2] / 255.0f;
+			}
+			float* px = out_rgb + ((size_t)y * (size_t)width + (size_t)x) * 3;
+			px[0] = color.x; px[1] = color.y; px[2] = color.z;             /* CS:342-345 */
+		}
+}
+
 void orc_quantize(const float* rgb, size_t n, uint8_t* out) {
 	for (size_t i = 0; i < n; i++) {
 		float c = rgb[i];

@@ -75,6 +75,12 @@ void orc_render_mt(const float* tris28, int n_tris, const float* lights4, int n_
                    const float cam_pos[3], const float trans16[16], int width, int height,
                    int max_bounces, int n_threads, float* out_rgb, orc_counters* ctr);
 
+/* Compute.shader:140-345, the reference's GL compute-shader renderer restated in IEEE binary32 (no mirrors,
+ * binary32 light scale, colour applied after the sum, no clamp) — PARITY UNPINNED, see rt_oracle.c.
+ * The checker of RT_SHADE_GLSL. */
+void orc_render_glsl(const float* tris28, int n_tris, const float* lights4, int n_lights,
+                     const float cam_pos[3], const float trans16[16], int width, int height, float* out_rgb);
+
 /* The GL unorm rule both sides of every 8-bit comparison use (note after the table):
  * q = (int)(c*255.0f + 0.5f), c<0 or NaN -> 0. */
 void orc_quantize(const float* rgb, size_t n, uint8_t* out);

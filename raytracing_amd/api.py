@@ -26,6 +26,7 @@ KERNEL_AUTO, KERNEL_STATE_MACHINE, KERNEL_LOCKSTEP = 0, 1, 2
 BUILD_FAST, BUILD_SAH = 0, 1
 STRICT = 0            # RT_RENDER_STRICT: the only render mode (bit-identical frames)
 OUT_RGBA8 = 0x100     # RT_OUT_RGBA8: the output buffer takes packed 8-bit pixels instead of three floats
+SHADE_GLSL = 0x200    # RT_SHADE_GLSL: the colour arithmetic of the reference's compute shader (Compute.shader:181-219, 330)
 STACK_LIMIT = 64      # RT_STACK_LIMIT
 NOALLOC_MAX_RAYS = 16384
 TRI_FLOATS = 28
@@ -462,19 +463,21 @@ class Scene:
     def render(self, cam_pos, trans16, width: int, height: int, max_bounces: int = 1,
                mode: int = STRICT) -> np.ndarray:
         """(H, W, 3) float32, data[(y*w+x)*3+c], row 0 = bottom — Source.cpp:550, 612-614; with
-        mode | OUT_RGBA8 the (H, W, 4) uint8 frame the reference's viewer displays (GL unorm, alpha 255)."""
+        mode | OUT_RGBA8 the (H, W, 4) uint8 frame the reference's viewer displays (GL unorm, alpha 255); with
+        mode | SHADE_GLSL the frame the reference's compute shader computes (no mirrors, no clamp; rt355.h)."""
         cam, tr = _f32(cam_pos), _f32(trans16)
         out = np.empty((height, width, 4), dtype=np.uint8) if mode & OUT_RGBA8 else np.empty((height, width, 3), dtype=np.float32)
         _check(lib().rt_render(self._h, _p(cam), _p(tr), width, height, max_bounces, mode, C.c_void_p(out.ctypes.data)))
         return out
 
-    def render_async(self, cam_pos, trans16, width: int, height: int, max_bounces: int, out: "HostFrame") -> int:
+    def render_async(self, cam_pos, trans16, width: int, height: int, max_bounces: int, out: "HostFrame",
+                     mode: int = STRICT) -> int:
         """rt_render_async into a pinned HostFrame (or any array of the frame's size: float32 RGB, or uint8 RGBA
         for an OUT_RGBA8 frame) -> ticket."""
         cam, tr = _f32(cam_pos), _f32(trans16)
         ptr = out.ptr if isinstance(out, HostFrame) else out.ctypes.data
         rgba8 = out.rgba8 if isinstance(out, HostFrame) else out.dtype == np.uint8
-        return _check(lib().rt_render_async(self._h, _p(cam), _p(tr), width, height, max_bounces, STRICT | (OUT_RGBA8 if rgba8 else 0), C.c_void_p(ptr)))
+        return _check(lib().rt_render_async(self._h, _p(cam), _p(tr), width, height, max_bounces, (mode & ~OUT_RGBA8) | (OUT_RGBA8 if rgba8 else 0), C.c_void_p(ptr)))
 
     def render_wait(self, ticket: int) -> None:
         _check(lib().rt_render_wait(self._h, int(ticket)))

@@ -96,9 +96,9 @@ int check_frame_args(const char* fn, const rt_scene* s, const float* cam, const 
 	return RT_OK;
 }
 
-int check_flags(const char* fn, int render_flags, bool rgba8_ok = false) {
-	if (rgba8_ok) render_flags &= ~RT_OUT_RGBA8;
-	if (render_flags != RT_RENDER_STRICT) { set_error("%s: unknown render flag %d (RT_RENDER_STRICT is the only mode)", fn, render_flags); return RT_ERR_INVALID; }
+int check_flags(const char* fn, int render_flags, bool format_bits_ok = false) {
+	if (format_bits_ok) render_flags &= ~(RT_OUT_RGBA8 | RT_SHADE_GLSL);
+	if (render_flags != RT_RENDER_STRICT) { set_error("%s: unknown render flag 0x%x (RT_RENDER_STRICT, with RT_OUT_RGBA8 / RT_SHADE_GLSL where the header allows them)", fn, render_flags); return RT_ERR_INVALID; }
 	return RT_OK;
 }
 
@@ -151,6 +151,7 @@ void fill_frame(rt_scene* s, FrameParams& fp, const float cam[3], const float tr
 	fp.tiles_per_wave = 0;
 	fp.out = nullptr;
 	fp.rgba8 = 0;
+	fp.shade_glsl = 0;
 	fp.counters = nullptr;
 }
 
@@ -410,6 +411,7 @@ int rt_render_tiles_device(rt_scene* s, int device, const float cam_pos[3], cons
 	fp.tiles_per_wave = s->tiles_per_wave;
 	fp.out = d_out_compact;
 	fp.rgba8 = (render_flags & RT_OUT_RGBA8) ? 1 : 0;
+	fp.shade_glsl = (render_flags & RT_SHADE_GLSL) ? 1 : 0;
 	return launch_render(dev_scene(s, *d), fp, d->accel, RT_RENDER_STRICT, false, (hipStream_t)hip_stream);
 }
 
@@ -441,6 +443,7 @@ int rt_render_frames_device(rt_scene* s, int device, int n_frames, const float* 
 		fp.tiles_per_wave = s->tiles_per_wave;
 		fp.out = d_out_rgb + (size_t)f0 * frame_stride_floats;
 		fp.rgba8 = rgba8 ? 1 : 0;
+		fp.shade_glsl = (render_flags & RT_SHADE_GLSL) ? 1 : 0;
 		rc = launch_render(sc, fp, d->accel, RT_RENDER_STRICT, false, (hipStream_t)hip_stream);
 		if (rc != RT_OK) return rc;
 	}

@@ -117,6 +117,7 @@ struct FrameParams {
 	int uv_fast;
 	float* out;             // local_rows * width * 3 floats, or (rgba8) local_rows * width packed 8-bit pixels
 	int rgba8;              // RT_OUT_RGBA8: store_pixel (rt_kernels.hip)
+	int shade_glsl;         // RT_SHADE_GLSL: the compute shader's colour arithmetic (render_kernel only; the launcher picks it)
 	unsigned long long* counters;   // rt_stats as 10 x u64, or null
 };
 

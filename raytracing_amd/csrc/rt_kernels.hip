@@ -978,7 +978,7 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 				finish = true;
 			} else {
 				if (COUNT) ctr[CTR_PXHIT]++;
-				if (N4.w > 0.5f) {                                           // Source.cpp:570
+				if (N4.w > 0.5f && !fp.shade_glsl) {                         // Source.cpp:570 (Compute.shader:257-330 has no mirrors)
 					bounces = 0;
 					stage = ST_BOUNCE;
 					mirror = true;                                           // Source.cpp:561, 572-573
@@ -1002,19 +1002,31 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 				finish = true;
 			}
 		} else if (stage == ST_SHADOW) {
-			if (!hit || h.t > dist) {                                        // Source.cpp:476
-				const float f = 1.0f / (dist * dist) * intensity;            // Source.cpp:488
-				const float modify = div65025(f);                            // ... / 255.0 / 255.0f: binary64 divisions, rounded to binary32
-				const float cr = tri_plane<ACCEL>(sc, s_tri, lds_stride, PL_P1, hidx).w;
-				const float cg = tri_plane<ACCEL>(sc, s_tri, lds_stride, PL_P2, hidx).w;
-				const float cb = tri_plane<ACCEL>(sc, s_tri, lds_stride, PL_P3, hidx).w;
-				color.x = color.x + modify * cr;                             // Source.cpp:489
-				color.y = color.y + modify * cg;
-				color.z = color.z + modify * cb;
+			if (!hit || h.t > dist) {                                        // Source.cpp:476, Compute.shader:203
+				const float f = 1.0f / (dist * dist) * intensity;            // Source.cpp:488, Compute.shader:214
+				if (fp.shade_glsl) {
+					color.x = color.x + f / 255.0f;                          // Compute.shader:214: the scalar `result`, all binary32
+				} else {
+					const float modify = div65025(f);                        // ... / 255.0 / 255.0f: binary64 divisions, rounded to binary32
+					const float cr = tri_plane<ACCEL>(sc, s_tri, lds_stride, PL_P1, hidx).w;
+					const float cg = tri_plane<ACCEL>(sc, s_tri, lds_stride, PL_P2, hidx).w;
+					const float cb = tri_plane<ACCEL>(sc, s_tri, lds_stride, PL_P3, hidx).w;
+					color.x = color.x + modify * cr;                         // Source.cpp:489
+					color.y = color.y + modify * cg;
+					color.z = color.z + modify * cb;
+				}
 				lit_any = true;
 			}
 			li++;
-			if (li >= sc.n_lights) finish = true;
+			if (li >= sc.n_lights) {
+				finish = true;
+				if (fp.shade_glsl) {                                         // Compute.shader:330: (indirect + direct) * hit.color / 255.0, indirect == 0
+					const float direct = 0.0f + color.x;
+					color.x = direct * tri_plane<ACCEL>(sc, s_tri, lds_stride, PL_P1, hidx).w / 255.0f;
+					color.y = direct * tri_plane<ACCEL>(sc, s_tri, lds_stride, PL_P2, hidx).w / 255.0f;
+					color.z = direct * tri_plane<ACCEL>(sc, s_tri, lds_stride, PL_P3, hidx).w / 255.0f;
+				}
+			}
 		}
 
 		if (mirror) {
@@ -1051,9 +1063,11 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 			if (COUNT && lit_any) ctr[CTR_PXLIT]++;
 			vec3 c = color;
 			c.x = c.x * dim; c.y = c.y * dim; c.z = c.z * dim;               // Source.cpp:586; dim == 1 (exact) on the matte and miss paths
-			if (c.x > 1.0f) c.x = 1.0f;                                      // Source.cpp:602-610
-			if (c.y > 1.0f) c.y = 1.0f;
-			if (c.z > 1.0f) c.z = 1.0f;
+			if (!fp.shade_glsl) {                                            // (Compute.shader:342-345 stores unclamped)
+				if (c.x > 1.0f) c.x = 1.0f;                                  // Source.cpp:602-610
+				if (c.y > 1.0f) c.y = 1.0f;
+				if (c.z > 1.0f) c.z = 1.0f;
+			}
 			store_pixel(fp, frame, out_index, c);
 			stage = ST_IDLE;
 			lit_any = false;
@@ -1322,7 +1336,7 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 	// 14.1 | 13.5 | 13.3 | 14.1, 1600x1600 - | - | 47.4 | 45.2, mirrors 3840x2160 255 | 242 | 236 | 233 | 239, room 7680x4320 653 | 613 | 585 | 567 | 573)
 	// AUTO is the lockstep form: measured faster than, or equal to, the state machine on every scene tried, up to
 	// depth 16 and with bounce depths that diverge inside a tile
-	const bool lockstep = !count && sc.kernel_kind != RT_KERNEL_STATE_MACHINE;
+	const bool lockstep = !count && sc.kernel_kind != RT_KERNEL_STATE_MACHINE && !fp.shade_glsl;   // (RT_SHADE_GLSL lives in render_kernel only)
 	int tpw = fp.tiles_per_wave > 0 ? fp.tiles_per_wave : (lockstep && accel != RT_ACCEL_LBVH ? (tiles * n_frames >= 128 * 8192 ? 2 * RT_LOCKSTEP_TILES : (tiles * n_frames >= 16 * 8192 ? RT_LOCKSTEP_TILES : (tiles * n_frames >= 4 * 8192 ? 2 : 1)))
 	                                                                                           : pick_tiles_per_wave(accel, tiles * n_frames));
 	// (tree kernels: one tile, except frames of 400k tiles and more — 102k triangles, measured 1 | 2 tiles: 3840x2160 214.6 | 222.7 us,

@@ -13,7 +13,7 @@
 // quad shows.  8-bit values use the GL unorm rule q = (int)(c*255.0f + 0.5f).
 //
 //   rt_headless [--scene stock|FILE] [--size W H] [--depth D] [--camera px py pz rx ry rz]
-//               [--frames N] [--async] [--rgba8] [--lbvh|--brute] [--device K]
+//               [--frames N] [--async] [--rgba8] [--glsl] [--lbvh|--brute] [--device K]
 //               [--txt Image.txt] [--ppm out.ppm] [--raw out.f32] [--rto model.rto]
 //               [--walk SCRIPT]
 //
@@ -43,6 +43,7 @@ struct Options {
 	float cam[6] = { -5, 5, 5, 135, -45, 0 };   // Source.cpp:810
 	bool cam_set = false;
 	int frames = 1;
+	bool glsl = false;          // --glsl: RT_SHADE_GLSL, the colour arithmetic of the reference's compute shader (rt355.h)
 	bool rgba8 = false;         // --rgba8: frames as RT_OUT_RGBA8 pixels (the 8 bits GL makes of `data`); images are written from them, --raw dumps them
 	bool pipelined = false;     // --async: rt_render_async into two pinned frames (the hand-off of Source.cpp:1270 overlapped with the next render)
 	int accel = RT_ACCEL_AUTO;
@@ -156,6 +157,7 @@ int main(int argc, char** argv) {
 		else if (a == "--frames") { need(1); o.frames = atoi(argv[++i]); }
 		else if (a == "--async") o.pipelined = true;
 		else if (a == "--rgba8") o.rgba8 = true;
+		else if (a == "--glsl") o.glsl = true;
 		else if (a == "--lbvh") o.accel = RT_ACCEL_LBVH;
 		else if (a == "--brute") o.accel = RT_ACCEL_BRUTE;
 		else if (a == "--device") { need(1); o.device = atoi(argv[++i]); }
@@ -207,7 +209,7 @@ int main(int argc, char** argv) {
 	rt_camera_init(&camera, o.cam, o.cam + 3);                          // Source.cpp:810
 	float trans[16];
 	const size_t n_floats = (size_t)o.width * o.height * (o.rgba8 ? 1 : 3);      // RT_OUT_RGBA8: one 4-byte pixel instead of three floats
-	const int flags = RT_RENDER_STRICT | (o.rgba8 ? RT_OUT_RGBA8 : 0);
+	const int flags = RT_RENDER_STRICT | (o.rgba8 ? RT_OUT_RGBA8 : 0) | (o.glsl ? RT_SHADE_GLSL : 0);
 	std::vector<float> data;                                            // Source.cpp:1035
 	float* pinned[2] = { nullptr, nullptr };
 	try {

@@ -60,6 +60,13 @@ def test_headless_walk_equals_oracle(tmp_path, oracle):
     assert blob.startswith(head)
     px8 = np.frombuffer(blob[len(head):], dtype=np.uint8).reshape(desc.height, desc.width, 3)
     assert np.array_equal(px8[::-1], oracle.quantize(want).reshape(desc.height, desc.width, 3))
+    # the same walk as the reference's compute shader would colour it (RT_SHADE_GLSL; its restatement is unpinned)
+    raw3 = tmp_path / "out_glsl.f32"
+    res = subprocess.run([EXE, "--scene", str(scene), "--walk", str(walk), "--raw", str(raw3), "--glsl"], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    want_glsl = oracle.render_glsl(tris, lights, cam.position, cam.trans(), desc.width, desc.height)
+    assert np.array_equal(_bits(np.fromfile(raw3, dtype=np.float32).reshape(desc.height, desc.width, 3)), _bits(want_glsl))
+    assert not np.array_equal(_bits(want_glsl), _bits(want))
     bad = subprocess.run([EXE, "--scene", str(scene), "--size", "-5", "64"], capture_output=True, text=True, timeout=60)
     assert bad.returncode == 2 and "not usable" in bad.stderr                     # (used to abort on the allocation)
 

@@ -76,7 +76,7 @@ def test_rgba8_through_the_tree_tiles_batches_and_the_async_hand_off(oracle):
         with pytest.raises(api.RtError):
             sc.render_multi([0], desc.cam_pos, tr, W, H, desc.depth, RGBA8)
         with pytest.raises(api.RtError):
-            sc.render(desc.cam_pos, tr, W, H, desc.depth, 0x200)
+            sc.render(desc.cam_pos, tr, W, H, desc.depth, 0x400)
 
 
 def test_unorm8_edge_values(oracle):
