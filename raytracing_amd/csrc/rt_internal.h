@@ -28,9 +28,10 @@ namespace rt {
 //   plane 10 CHI[c] = (upper corner,              group count as int bits)   consecutive groups
 //   plane 11 COL = (color.r, color.g, color.b, shininess): what shading reads by hit index, in one load
 // The `p` field of the reference record (Source.cpp:33, always == p1) is not uploaded.
-enum { PL_N = 0, PL_P1, PL_P2, PL_P3, PL_E0, PL_E1, PL_E2, PL_GLO, PL_GHI, PL_CLO, PL_CHI, PL_COL, PL_COUNT };
+enum { PL_N = 0, PL_P1, PL_P2, PL_P3, PL_E0, PL_E1, PL_E2, PL_GLO, PL_GHI, PL_CLO, PL_CHI, PL_COL, PL_M0, PL_M1, PL_M2, PL_COUNT };   // PL_M*: edge_filter_planes (rt_scene.cpp)
 #define RT_CLUSTER_MAX_GROUPS 16
 #define RT_BVH4_EMPTY 0x7ffffffe     /* unused child slot of a 4-wide node */
+#define RT_AOS_F4 10                 /* float4 per triangle record of DevScene::tri_aos and DevScene::hoist */
 #ifndef RT_GROUP
 #define RT_GROUP 2
 #endif
@@ -53,7 +54,8 @@ struct DevScene {
 	// LBVH (null for brute force): see rt_lbvh.hip
 	const float4* bvh_nodes;   // binary Karras tree, 4 float4 per node (kept for inspection)
 	const uint4* bvh4;         // 4-wide quantised collapse of it, 64 B per node: what traversal walks
-	const float4* tri_aos;     // 8 float4 per triangle (N P1 P2 P3 E0 E1 E2 -): one burst per leaf test
+	const float4* tri_aos;     // RT_AOS_F4 float4 per triangle (N P1 M0 M1 M2 | P2 P3 E0 E1 E2): what a leaf test needs first, then what only the
+	                           // reference's own edge arithmetic needs (rt_kernels.hip edge_filter)
 	int bvh_root;
 	int skip_count;            // inner nodes per octant of the packet records (0: none)
 	// Wave-uniform ("packet") traversal of the same binary tree (rt_kernels.hip cast_ray_packet):
@@ -62,7 +64,7 @@ struct DevScene {
 	const float4* skiplist;
 	// Triangles whose box spans a large part of the scene (walls, a ground plane) are kept OUT of
 	// the tree, where each would inflate every box on its path to the root, and are tested first
-	// for every ray from this list (rt_lbvh.hip lbvh_build): hoist_count records of 8 float4 as in
+	// for every ray from this list (rt_lbvh.hip lbvh_build): hoist_count records of RT_AOS_F4 float4 as in
 	// tri_aos, ascending by triangle index, then for each of the 8 octants hoist_count padded boxes
 	// of 8 floats (near.xyz, far.xyz, -, triangle index as int bits) as in the octant records above.
 	const float4* hoist;

@@ -138,23 +138,55 @@ typedef unsigned long long lanemask;
 __device__ __forceinline__ lanemask lanes(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 __device__ __forceinline__ bool lane_in(lanemask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
+// The signs of the three edge terms of Source.cpp:392-394 without their 51 operations, where that is safe: with
+// M_k = n x edge_k made on the host (rt_scene.cpp edge_filter_planes, which holds the error analysis) and w = I - p1,
+// s_k = M_k . w - c_k has the sign of the reference's dot(n, cross(edge_k, I - p_k)) whenever |s_k| exceeds
+// B = G |w|_1 + H, a bound on the rounding of both.  Returns the candidate lanes that pass all three tests for sure;
+// `undecided` gets the candidates for which some term is inside its bound and no other term surely fails — those
+// lanes (a hit point within ~2^-20 of the triangle's size of an edge line) take the reference's own arithmetic.
+// M0.w = G, M1.w = c_1, M2.w = H.
+__device__ __forceinline__ lanemask edge_filter(float4 M0, float4 M1, float4 M2, vec3 w, lanemask cand, lanemask& undecided) {
+	const float w1 = (fabsf(w.x) + fabsf(w.y)) + fabsf(w.z);
+	// below 1e-20 the bound is raised to it (underflow cannot add that much); above 1e20, or NaN, nothing is decided
+	// (a bound that is NaN or infinite — a ray or a triangle that is not finite — fails the comparison with 1e20 before fmaxf drops it;
+	// within the guard every partial product is below 1e27: no term can be NaN)
+	const float B0 = __builtin_fmaf(M0.w, w1, M2.w);
+	const float B = fmaxf(B0, 1e-20f);
+	const float s0 = __builtin_fmaf(M0.x, w.x, __builtin_fmaf(M0.y, w.y, M0.z * w.z));
+	const float s1 = __builtin_fmaf(M1.x, w.x, __builtin_fmaf(M1.y, w.y, __builtin_fmaf(M1.z, w.z, -M1.w)));
+	const float s2 = __builtin_fmaf(M2.x, w.x, __builtin_fmaf(M2.y, w.y, M2.z * w.z));
+	const float least = fminf(fminf(s0, s1), s2);
+	const lanemask passes = lanes(least > B);                  // every term surely positive
+	const lanemask fails = lanes(-least > B);                  // the smallest term surely negative: some test of Source.cpp:392-394 fails
+	undecided = cand & ~((fails | passes) & lanes(B0 < 1e20f));
+	return cand & passes & ~undecided;
+}
+
 // Edge tests and acceptance for ONE triangle whose exact t is known (Source.cpp:389-396).
 template <typename TriPtr>
 __device__ __forceinline__ void accept_triangle(TriPtr tri, int stride, int i, vec3 nn, vec3 p1, vec3 o, vec3 d, float t,
                                                 lanemask cand, int skip, bool first_only, Hit& h, float& lim, float& lim_hi, WaveProf& wp) {
 	const vec3 I = make3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);   // Source.cpp:389
-	const float4 E0 = tri[PL_E0 * stride + i];
-	const lanemask c0 = cand & lanes(dot(nn, cross(xyz(E0), I - p1)) > 0.0f);    // Source.cpp:392
-	if (c0 == 0) return;
-	RT_PROF(wp, WP_C0);
-	const float4 P24 = tri[PL_P2 * stride + i];
-	const float4 E1 = tri[PL_E1 * stride + i];
-	const lanemask c1 = c0 & lanes(dot(nn, cross(xyz(E1), I - xyz(P24))) > 0.0f);   // Source.cpp:393
-	if (c1 == 0) return;
-	RT_PROF(wp, WP_C1);
-	const float4 P34 = tri[PL_P3 * stride + i];
-	const float4 E2 = tri[PL_E2 * stride + i];
-	const lanemask c2 = c1 & lanes(dot(nn, cross(xyz(E2), I - xyz(P34))) > 0.0f) & lanes(i != skip);   // Source.cpp:394, 302
+	const vec3 w = I - p1;
+	lanemask open;
+	lanemask c2 = edge_filter(tri[PL_M0 * stride + i], tri[PL_M1 * stride + i], tri[PL_M2 * stride + i], w, cand, open);
+	if (open != 0) {                                                        // some lane too close to an edge line to call: the reference's arithmetic
+		const float4 E0 = tri[PL_E0 * stride + i];
+		const lanemask c0 = open & lanes(dot(nn, cross(xyz(E0), w)) > 0.0f);            // Source.cpp:392
+		RT_PROF(wp, WP_C0);
+		if (c0 != 0) {
+			const float4 P24 = tri[PL_P2 * stride + i];
+			const float4 E1 = tri[PL_E1 * stride + i];
+			const lanemask c1 = c0 & lanes(dot(nn, cross(xyz(E1), I - xyz(P24))) > 0.0f);   // Source.cpp:393
+			RT_PROF(wp, WP_C1);
+			if (c1 != 0) {
+				const float4 P34 = tri[PL_P3 * stride + i];
+				const float4 E2 = tri[PL_E2 * stride + i];
+				c2 |= c1 & lanes(dot(nn, cross(xyz(E2), I - xyz(P34))) > 0.0f);         // Source.cpp:394
+			}
+		}
+	}
+	c2 &= lanes(i != skip);                                                 // Source.cpp:302
 	if (c2 == 0) return;
 	RT_PROF(wp, WP_ACCEPT);
 	if (lane_in(c2)) {                                                      // Source.cpp:396
@@ -359,15 +391,21 @@ __device__ __forceinline__ void packet_leaf(c4ptr T, int i, vec3 o, vec3 d, int 
 	if constexpr (COUNT) { const bool act = lim >= 0.0f && i != skip; lc.plane += act; lc.point += act && !(t < 0.0f); lc.edge += act && lane_in(cand); }
 	if (cand == 0) return;
 	RT_PROF(wp, WP_CAND);
-	const float4 P24 = T[2], P34 = T[3], E0 = T[4], E1 = T[5], E2 = T[6];   // the rest of the record in one go (wider loads were measured slower: SGPR pressure)
 	const vec3 I = make3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);      // Source.cpp:389
-	const lanemask c0 = cand & lanes(dot(nn, cross(xyz(E0), I - p1)) > 0.0f);       // Source.cpp:392
-	if constexpr (COUNT) lc.edge += lane_in(c0) && i != skip;
-	if (c0 == 0) return;
-	const lanemask c1 = c0 & lanes(dot(nn, cross(xyz(E1), I - xyz(P24))) > 0.0f);   // Source.cpp:393
-	if constexpr (COUNT) lc.edge += lane_in(c1) && i != skip;
-	if (c1 == 0) return;
-	const lanemask c2 = c1 & lanes(dot(nn, cross(xyz(E2), I - xyz(P34))) > 0.0f) & lanes(i != skip);   // Source.cpp:394, 302
+	const vec3 w = I - p1;
+	lanemask open = cand, c2 = 0;
+	if constexpr (!COUNT) c2 = edge_filter(T[2], T[3], T[4], w, cand, open);       // (the counting kernel takes the reference's steps one by one)
+	if (open != 0) {
+		const float4 P24 = T[5], P34 = T[6], E0 = T[7], E1 = T[8], E2 = T[9];
+		const lanemask c0 = open & lanes(dot(nn, cross(xyz(E0), w)) > 0.0f);            // Source.cpp:392
+		if constexpr (COUNT) lc.edge += lane_in(c0) && i != skip;
+		if (c0 != 0) {
+			const lanemask c1 = c0 & lanes(dot(nn, cross(xyz(E1), I - xyz(P24))) > 0.0f);   // Source.cpp:393
+			if constexpr (COUNT) lc.edge += lane_in(c1) && i != skip;
+			if (c1 != 0) c2 |= c1 & lanes(dot(nn, cross(xyz(E2), I - xyz(P34))) > 0.0f);   // Source.cpp:394
+		}
+	}
+	c2 &= lanes(i != skip);                                                 // Source.cpp:302
 	if (c2 == 0) return;
 	if (lane_in(c2)) {                                                      // Source.cpp:396
 		h.t = t; h.idx = i; h.p = I;
@@ -400,7 +438,7 @@ __device__ __forceinline__ Hit cast_ray_packet(const DevScene& sc, int oct, vec3
 	if (sc.hoist_count > 0) {
 		// the triangles kept out of the tree (DevScene::hoist), each behind its octant-ordered box
 		const c4ptr hrec = c4ptr_of(sc.hoist);
-		const c4ptr hbox = hrec.offset_floats((unsigned int)sc.hoist_count * 32u + (unsigned int)oct * (unsigned int)sc.hoist_count * 8u);
+		const c4ptr hbox = hrec.offset_floats((unsigned int)sc.hoist_count * (RT_AOS_F4 * 4u) + (unsigned int)oct * (unsigned int)sc.hoist_count * 8u);
 		for (int j = 0; j < sc.hoist_count;) {
 			const c4ptr R = hbox.offset_floats((unsigned int)j * 8u);
 			const float4 a0 = R[0], a1 = R[1];
@@ -408,8 +446,8 @@ __device__ __forceinline__ Hit cast_ray_packet(const DevScene& sc, int oct, vec3
 			RT_PROF(wp, WP_INBOX);
 			if constexpr (COUNT) lc.box += lim >= 0.0f;
 			if (__builtin_amdgcn_ballot_w64(slab_hit_oct(a0, a1, inv, oi, lim_hi)) != 0) {
-				packet_leaf<COUNT>(hrec.offset_floats((unsigned int)j * 32u), __float_as_int(a1.w), o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp);
-				if (second >= 0) packet_leaf<COUNT>(hrec.offset_floats((unsigned int)(j + 1) * 32u), second, o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp);
+				packet_leaf<COUNT>(hrec.offset_floats((unsigned int)j * (RT_AOS_F4 * 4u)), __float_as_int(a1.w), o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp);
+				if (second >= 0) packet_leaf<COUNT>(hrec.offset_floats((unsigned int)(j + 1) * (RT_AOS_F4 * 4u)), second, o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp);
 			}
 			j += second >= 0 ? 2 : 1;
 		}
@@ -427,14 +465,14 @@ __device__ __forceinline__ Hit cast_ray_packet(const DevScene& sc, int oct, vec3
 		const bool hitA = __builtin_amdgcn_ballot_w64(slab_hit_oct(q0, q1, inv, oi, lim_hi)) != 0;
 		int next = -1;
 		if (hitA) {
-			if (refA < 0) packet_leaf<COUNT>(aos.offset_floats((unsigned int)(~refA) * 32u), ~refA, o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp);
+			if (refA < 0) packet_leaf<COUNT>(aos.offset_floats((unsigned int)(~refA) * (RT_AOS_F4 * 4u)), ~refA, o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp);
 			else next = refA;
 		}
 		// the farther child is tested after a near LEAF has had its chance to shorten the limits
 		if constexpr (COUNT) lc.box += lim >= 0.0f;
 		const bool hitB = __builtin_amdgcn_ballot_w64(slab_hit_oct(q2, q3, inv, oi, lim_hi)) != 0;
 		if (hitB) {
-			if (refB < 0) packet_leaf<COUNT>(aos.offset_floats((unsigned int)(~refB) * 32u), ~refB, o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp);
+			if (refB < 0) packet_leaf<COUNT>(aos.offset_floats((unsigned int)(~refB) * (RT_AOS_F4 * 4u)), ~refB, o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp);
 			else if (next >= 0) wave_set_lane(stackv, refB, sp++);
 			else next = refB;
 		}
@@ -465,7 +503,7 @@ template <bool COUNT>
 __device__ __forceinline__ void hoisted_tests(const DevScene& sc, vec3 o, vec3 d, vec3 inv, vec3 oi, int skip, bool live, bool first_only,
                                               Hit& h, float& lim, float& lim_hi, LaneCounters& lc, WaveProf& wp) {
 	c4ptr T = c4ptr_of(sc.hoist);
-	c4ptr B = T.offset_floats((unsigned int)sc.hoist_count * 32u);                           // octant 0: near = lo, far = hi
+	c4ptr B = T.offset_floats((unsigned int)sc.hoist_count * (RT_AOS_F4 * 4u));                           // octant 0: near = lo, far = hi
 	for (int j = 0; j < sc.hoist_count;) {
 		const float4 b0 = B[0], b1 = B[1];
 		const int second = __float_as_int(b1.z);             // a partner with the same box follows (rt_lbvh.hip k_hoist), or -1
@@ -474,7 +512,7 @@ __device__ __forceinline__ void hoisted_tests(const DevScene& sc, vec3 o, vec3 d
 		const bool meets = __builtin_amdgcn_ballot_w64(live && slab_hit(b0, make_float4(b0.w, b1.x, b1.y, 0.f), inv, oi, lim_hi)) != 0;
 		for (int m = 0; m < members && meets; m++) {
 			RT_PROF(wp, WP_TRI);
-			const c4ptr Tm = T.offset_floats(32 * m);
+			const c4ptr Tm = T.offset_floats((RT_AOS_F4 * 4) * m);
 			const int i = m == 0 ? __float_as_int(b1.w) : second;
 			const float4 N4 = Tm[0], P14 = Tm[1];
 			const vec3 nn = xyz(N4), p1 = xyz(P14);
@@ -483,15 +521,21 @@ __device__ __forceinline__ void hoisted_tests(const DevScene& sc, vec3 o, vec3 d
 			const lanemask cand = visit & lanes(t > RT_EPS_BELOW) & lanes(t < lim); // Source.cpp:385, 391
 			if constexpr (COUNT) { lc.plane += lane_in(visit); lc.point += lane_in(visit) && !(t < 0.0f); lc.edge += lane_in(cand); }
 			if (cand == 0) continue;
-			const float4 P24 = Tm[2], P34 = Tm[3], E0 = Tm[4], E1 = Tm[5], E2 = Tm[6];
 			const vec3 I = make3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);      // Source.cpp:389
-			const lanemask c0 = cand & lanes(dot(nn, cross(xyz(E0), I - p1)) > 0.0f);       // Source.cpp:392
-			if constexpr (COUNT) lc.edge += lane_in(c0);
-			if (c0 == 0) continue;
-			const lanemask c1 = c0 & lanes(dot(nn, cross(xyz(E1), I - xyz(P24))) > 0.0f);   // Source.cpp:393
-			if constexpr (COUNT) lc.edge += lane_in(c1);
-			if (c1 == 0) continue;
-			const lanemask c2 = c1 & lanes(dot(nn, cross(xyz(E2), I - xyz(P34))) > 0.0f);   // Source.cpp:394
+			const vec3 w = I - p1;
+			lanemask open = cand, c2 = 0;
+			if constexpr (!COUNT) c2 = edge_filter(Tm[2], Tm[3], Tm[4], w, cand, open);
+			if (open != 0) {
+				const float4 P24 = Tm[5], P34 = Tm[6], E0 = Tm[7], E1 = Tm[8], E2 = Tm[9];
+				const lanemask c0 = open & lanes(dot(nn, cross(xyz(E0), w)) > 0.0f);            // Source.cpp:392
+				if constexpr (COUNT) lc.edge += lane_in(c0);
+				if (c0 != 0) {
+					const lanemask c1 = c0 & lanes(dot(nn, cross(xyz(E1), I - xyz(P24))) > 0.0f);   // Source.cpp:393
+					if constexpr (COUNT) lc.edge += lane_in(c1);
+					if (c1 != 0) c2 |= c1 & lanes(dot(nn, cross(xyz(E2), I - xyz(P34))) > 0.0f);   // Source.cpp:394
+				}
+			}
+			if (c2 == 0) continue;
 			if (lane_in(c2)) {                                                      // Source.cpp:396
 				h.t = t; h.idx = i; h.p = I;
 				lim = first_only ? -1.0f : t;
@@ -499,7 +543,7 @@ __device__ __forceinline__ void hoisted_tests(const DevScene& sc, vec3 o, vec3 d
 			}
 		}
 		j += members;
-		T = T.offset_floats(32 * members);
+		T = T.offset_floats((RT_AOS_F4 * 4) * members);
 		B = B.offset_floats(8 * members);
 	}
 }

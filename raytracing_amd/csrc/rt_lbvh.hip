@@ -275,20 +275,25 @@ __global__ void __launch_bounds__(256) k_collapse4(const float4* __restrict__ no
 	o[3] = make_uint4(qh[1], qh[2], 0u, 0u);
 }
 
+__device__ __forceinline__ void aos_record(const float4* __restrict__ planes, int stride, int i, float4* __restrict__ o) {
+	o[0] = planes[PL_N * stride + i];
+	o[1] = planes[PL_P1 * stride + i];
+	o[2] = planes[PL_M0 * stride + i];
+	o[3] = planes[PL_M1 * stride + i];
+	o[4] = planes[PL_M2 * stride + i];
+	o[5] = planes[PL_P2 * stride + i];
+	o[6] = planes[PL_P3 * stride + i];
+	o[7] = planes[PL_E0 * stride + i];
+	o[8] = planes[PL_E1 * stride + i];
+	o[9] = planes[PL_E2 * stride + i];
+}
+
 // 6. k_aos: the SoA planes regrouped per triangle so that a leaf test is ONE burst of loads
 //    (N, P1 and, for candidates, the edge data) instead of up to four dependent round trips.
 __global__ void __launch_bounds__(256) k_aos(const float4* __restrict__ planes, int stride, int n, float4* __restrict__ out) {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
-	float4* o = out + (size_t)i * 8;
-	o[0] = planes[PL_N * stride + i];
-	o[1] = planes[PL_P1 * stride + i];
-	o[2] = planes[PL_P2 * stride + i];
-	o[3] = planes[PL_P3 * stride + i];
-	o[4] = planes[PL_E0 * stride + i];
-	o[5] = planes[PL_E1 * stride + i];
-	o[6] = planes[PL_E2 * stride + i];
-	o[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+	aos_record(planes, stride, i, out + (size_t)i * RT_AOS_F4);
 }
 
 // 7. k_packet: per octant, the node's two children with the one nearer along that octant first and
@@ -345,20 +350,12 @@ __global__ void __launch_bounds__(64) k_hoist(const float4* __restrict__ planes,
 	__shared__ float s_lo[RT_HOIST_MAX][3], s_hi[RT_HOIST_MAX][3];
 	__shared__ int s_second[RT_HOIST_MAX];       // triangle index of the partner that follows, or -1
 	const int j = threadIdx.x;
-	float4* boxes = out + (size_t)k * 8;
+	float4* boxes = out + (size_t)k * RT_AOS_F4;
 	int i = 0;
 	if (j < k) {
 		i = idx[j];
 		keys[i] = (1ull << 63) | (u64)(unsigned int)i;
-		float4* o = out + (size_t)j * 8;
-		o[0] = planes[PL_N * stride + i];
-		o[1] = planes[PL_P1 * stride + i];
-		o[2] = planes[PL_P2 * stride + i];
-		o[3] = planes[PL_P3 * stride + i];
-		o[4] = planes[PL_E0 * stride + i];
-		o[5] = planes[PL_E1 * stride + i];
-		o[6] = planes[PL_E2 * stride + i];
-		o[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+		aos_record(planes, stride, i, out + (size_t)j * RT_AOS_F4);
 		float lo[3], hi[3];
 		tri_box_padded(planes, stride, i, pad, lo, hi);
 		for (int a = 0; a < 3; a++) { s_lo[j][a] = lo[a]; s_hi[j][a] = hi[a]; }
@@ -486,7 +483,7 @@ int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 	const int nh = (int)hoisted.size();
 	const int nt = n - nh;                       // triangles in the tree
 	const bool sah = s->build == RT_BUILD_SAH;
-	const size_t hoist_float4s = (size_t)nh * (8 + 8 * 2);   // records, then 8 octants of boxes
+	const size_t hoist_float4s = (size_t)nh * (RT_AOS_F4 + 8 * 2);   // records, then 8 octants of boxes
 	int* hoist_idx = nullptr;
 	float4* hoist = nullptr;
 	u64 *keys = nullptr, *keys_sorted = nullptr;
@@ -517,7 +514,7 @@ int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 	LB_TRY(dev_alloc(&flags, (size_t)n));
 	LB_TRY(dev_alloc(&nodes, (size_t)(nt - 1) * 4));
 	LB_TRY(dev_alloc(&nodes4, (size_t)(nt - 1) * 4));
-	LB_TRY(dev_alloc(&aos, (size_t)n * 8));
+	LB_TRY(dev_alloc(&aos, (size_t)n * RT_AOS_F4));
 	const bool want_packet = true;
 	LB_TRY(dev_alloc(&pkt, (size_t)(nt - 1) * 4 * 8));
 	if (nh > 0) {

@@ -199,8 +199,8 @@ __device__ __forceinline__ Hit cast_ray_lbvh(const DevScene& sc, int* lds_stack,
 #endif
 		if (leaf_trip && has) {
 			const int i = ~pend;
-			const float4* T = (const float4*)((const char*)sc.tri_aos + (unsigned int)i * 128u);
-			const float4 N4 = T[0], P14 = T[1], P24 = T[2], P34 = T[3], E0 = T[4], E1 = T[5], E2 = T[6];
+			const float4* T = (const float4*)((const char*)sc.tri_aos + (unsigned int)i * (RT_AOS_F4 * 16u));
+			const float4 N4 = T[0], P14 = T[1], M0 = T[2], M1 = T[3], M2 = T[4];             // (the edge data only if the filter leaves a lane open)
 			const vec3 nn = xyz(N4), p1 = xyz(P14);
 			const float t = dot(p1 - o, nn) / dot(d, nn);                                 // Source.cpp:383
 			// lane predicates as wave masks (rt_kernels.hip lanemask); the lanes of this leaf trip only
@@ -211,19 +211,23 @@ __device__ __forceinline__ Hit cast_ray_lbvh(const DevScene& sc, int* lds_stack,
 			lanemask found_m = 0;
 			if (cand != 0) {
 				const vec3 I = make3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);        // Source.cpp:389
-				const lanemask c0 = cand & lanes(dot(nn, cross(xyz(E0), I - p1)) > 0.0f); // Source.cpp:392
-				if (COUNT) lc.edge += lane_in(c0);
-				if (c0 != 0) {
-					const lanemask c1 = c0 & lanes(dot(nn, cross(xyz(E1), I - xyz(P24))) > 0.0f);   // Source.cpp:393
-					if (COUNT) lc.edge += lane_in(c1);
-					if (c1 != 0) {
-						found_m = c1 & lanes(dot(nn, cross(xyz(E2), I - xyz(P34))) > 0.0f);         // Source.cpp:394
-						if (lane_in(found_m)) {
-							h.t = t; h.idx = i; h.p = I;                                  // Source.cpp:396
-							lim = t;
-							lim_hi = lim + fabsf(lim) * RT_PREFILTER_REL;
-						}
+				const vec3 w = I - p1;
+				lanemask open = cand;
+				if (!COUNT) found_m = edge_filter(M0, M1, M2, w, cand, open);             // rt_kernels.hip; the counting kernel takes the reference's steps
+				if (open != 0) {
+					const float4 P24 = T[5], P34 = T[6], E0 = T[7], E1 = T[8], E2 = T[9];
+					const lanemask c0 = open & lanes(dot(nn, cross(xyz(E0), w)) > 0.0f);  // Source.cpp:392
+					if (COUNT) lc.edge += lane_in(c0);
+					if (c0 != 0) {
+						const lanemask c1 = c0 & lanes(dot(nn, cross(xyz(E1), I - xyz(P24))) > 0.0f);   // Source.cpp:393
+						if (COUNT) lc.edge += lane_in(c1);
+						if (c1 != 0) found_m |= c1 & lanes(dot(nn, cross(xyz(E2), I - xyz(P34))) > 0.0f);   // Source.cpp:394
 					}
+				}
+				if (lane_in(found_m)) {
+					h.t = t; h.idx = i; h.p = I;                                          // Source.cpp:396
+					lim = t;
+					lim_hi = lim + fabsf(lim) * RT_PREFILTER_REL;
 				}
 			}
 			const bool found = lane_in(found_m);

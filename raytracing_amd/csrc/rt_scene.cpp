@@ -154,6 +154,58 @@ float scene_box(const std::vector<float>& tris, float lo[3], float hi[3]) {
 	return pad;
 }
 
+// The sign filter for the three edge terms of Source.cpp:392-394 (kernels: edge_signs in rt_kernels.hip).
+// The reference evaluates  v_k = dot(n, cross(edge_k, I - p_k))  in binary32, 17 operations per edge, and only the
+// SIGN of the result is used.  In real arithmetic  v_k = M_k . (I - p_k)  with  M_k = n x edge_k  (scalar triple
+// product), and with w = I - p1:  v_0 = M_0 . w,  v_1 = M_1 . w - c_1  (c_1 = M_1 . (p2 - p1)),  v_2 = M_2 . w - c_2  where
+// c_2 = M_2 . (p3 - p1) is zero up to the rounding of the stored edge_2 = fl(p1 - p3).  The kernels evaluate
+// s_k = fma(M_k.x, w.x, fma(M_k.y, w.y, fma(M_k.z, w.z, -c_k)))  (c_0 = c_2 = 0) and trust its sign only when
+// |s_k| > G * (|w.x| + |w.y| + |w.z|) + H; every other lane takes the reference's own 17 operations.
+// Error budget, u = 2^-24, A = (|n.x|+|n.y|+|n.z|) * max_k (|e_k.x|+|e_k.y|+|e_k.z|), |w| the largest component of w:
+//   the reference's value against the real one: 6 roundings on the longest path (w_k, product, cross, product, two sums)
+//     of terms bounded by A * |w_k|, |w_k| <= |w| + |p_k - p1|                       <= 6 u A (|w| + E)
+//   s_k against the real one: M_k rounded from binary64 (u A |w|), c_1 rounded (u A E), c_2 dropped (u A E),
+//     three fma roundings of partial sums bounded by A (|w| + E)                      <= 5 u A (|w| + E)
+// with E = max(|p2 - p1|_1, |p3 - p1|_1).  11 u A (|w| + E) <= G |w|_1 + H for G = 16 u A, H = G E (both rounded up by
+// 2^-10) — no product may overflow or leave the normal range for this to hold, which the kernels make sure of by
+// trusting the filter only for 1e-20 < G |w|_1 + H < 1e20 (all partial results are then below 1e27, and what underflow
+// can add is 40 orders of magnitude below the threshold).  A degenerate triangle (n not finite) gets G = NaN:
+// never trusted.
+static void edge_filter_planes(const float* t, float* m0, float* m1, float* m2) {
+	const float* nrm = t + 3; const float* p1 = t + 6; const float* p2 = t + 9; const float* p3 = t + 12;
+	const float* e[3] = { t + 15, t + 18, t + 21 };
+	float* m[3] = { m0, m1, m2 };
+	double n1 = fabs((double)nrm[0]) + fabs((double)nrm[1]) + fabs((double)nrm[2]), emax = 0.0;
+	double M[3][3];
+	for (int k = 0; k < 3; k++) {
+		const double ex = e[k][0], ey = e[k][1], ez = e[k][2], nx = nrm[0], ny = nrm[1], nz = nrm[2];
+		M[k][0] = ny * ez - nz * ey;          // (n x e): products of two binary32 values are exact in binary64
+		M[k][1] = nz * ex - nx * ez;
+		M[k][2] = nx * ey - ny * ex;
+		for (int c = 0; c < 3; c++) m[k][c] = (float)M[k][c];
+		const double e1n = fabs(ex) + fabs(ey) + fabs(ez);
+		if (e1n > emax) emax = e1n;
+	}
+	double d2[3], d3[3], E2 = 0.0, E3 = 0.0, c1 = 0.0;
+	for (int c = 0; c < 3; c++) {
+		d2[c] = (double)p2[c] - (double)p1[c];
+		d3[c] = (double)p3[c] - (double)p1[c];
+		E2 += fabs(d2[c]);
+		E3 += fabs(d3[c]);
+		c1 += M[1][c] * d2[c];
+	}
+	const double up = 1.0 + 1.0 / 1024.0;
+	const double G = 16.0 * (1.0 / 16777216.0) * n1 * emax * up;
+	const double H = G * (E2 > E3 ? E2 : E3) * up;
+	m0[3] = (float)(G * up);                  // (the conversions round to nearest: the second 2^-10 covers them)
+	m1[3] = (float)c1;
+	m2[3] = (float)(H * up);
+	// a filter that cannot be trusted for this triangle: G = NaN sends every lane to the reference's arithmetic
+	bool ok = G - G == 0.0 && H - H == 0.0 && c1 - c1 == 0.0 && fabs(c1) < 1e30;
+	for (int k = 0; k < 3 && ok; k++) for (int c = 0; c < 3; c++) if (!(fabs(M[k][c]) < 1e30)) ok = false;
+	if (!ok) m0[3] = __builtin_nanf("");
+}
+
 PlaneLayout flatten_planes(const std::vector<float>& tris, int stride, float pad, bool with_octant_records, std::vector<float>& out) {
 	const int n = (int)(tris.size() / RT_TRI_FLOATS);
 	const float inf = __builtin_huge_valf();
@@ -172,6 +224,7 @@ PlaneLayout flatten_planes(const std::vector<float>& tris, int stride, float pad
 		q = plane(PL_E1, i); q[0] = e1[0]; q[1] = e1[1]; q[2] = e1[2];
 		q = plane(PL_E2, i); q[0] = e2[0]; q[1] = e2[1]; q[2] = e2[2];
 		q = plane(PL_COL, i); q[0] = col[0]; q[1] = col[1]; q[2] = col[2]; q[3] = t[27];
+		edge_filter_planes(t, plane(PL_M0, i), plane(PL_M1, i), plane(PL_M2, i));
 	}
 	// padded boxes of groups of RT_GROUP consecutive triangles
 	for (int g = 0; g < stride; g++) {      // every slot past the last group is an empty box
