@@ -435,24 +435,6 @@ __device__ __forceinline__ Hit cast_ray_packet(const DevScene& sc, int oct, vec3
 #ifdef RT_PROFILE
 	int steps_ = 0;
 #endif
-	if (sc.hoist_count > 0) {
-		// the triangles kept out of the tree (DevScene::hoist), each behind its octant-ordered box
-		const c4ptr hrec = c4ptr_of(sc.hoist);
-		const c4ptr hbox = hrec.offset_floats((unsigned int)sc.hoist_count * (RT_AOS_F4 * 4u) + (unsigned int)oct * (unsigned int)sc.hoist_count * 8u);
-		for (int j = 0; j < sc.hoist_count;) {
-			const c4ptr R = hbox.offset_floats((unsigned int)j * 8u);
-			const float4 a0 = R[0], a1 = R[1];
-			const int second = __float_as_int(a1.z);         // a partner with the same box follows (rt_lbvh.hip k_hoist), or -1
-			RT_PROF(wp, WP_INBOX);
-			if constexpr (COUNT) lc.box += lim >= 0.0f;
-			if (__builtin_amdgcn_ballot_w64(slab_hit_oct(a0, a1, inv, oi, lim_hi)) != 0) {
-				packet_leaf<COUNT>(hrec.offset_floats((unsigned int)j * (RT_AOS_F4 * 4u)), __float_as_int(a1.w), o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp);
-				if (second >= 0) packet_leaf<COUNT>(hrec.offset_floats((unsigned int)(j + 1) * (RT_AOS_F4 * 4u)), second, o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp);
-			}
-			j += second >= 0 ? 2 : 1;
-		}
-		if (__builtin_amdgcn_ballot_w64(lim >= 0.0f) == 0) return h;            // (shadow rays that all have their hit)
-	}
 	int stackv = 0;          // wave-uniform stack: entry k lives in lane k (a Karras tree over 63 key bits is at most 63 deep)
 	int sp = 0;
 	int node = 0;
@@ -485,6 +467,25 @@ __device__ __forceinline__ Hit cast_ray_packet(const DevScene& sc, int oct, vec3
 #ifdef RT_PROFILE
 		steps_++;
 #endif
+	}
+	// The triangles kept out of the tree (DevScene::hoist), each behind its octant-ordered box — AFTER the walk: they are the
+	// scene-spanning ones (the walls of the reference's room), mostly behind what the tree holds, and with the limits the walk
+	// leaves their boxes are only met where a ray still has to reach them.
+	if (sc.hoist_count > 0 && __builtin_amdgcn_ballot_w64(lim >= 0.0f) != 0) {
+		const c4ptr hrec = c4ptr_of(sc.hoist);
+		const c4ptr hbox = hrec.offset_floats((unsigned int)sc.hoist_count * (RT_AOS_F4 * 4u) + (unsigned int)oct * (unsigned int)sc.hoist_count * 8u);
+		for (int j = 0; j < sc.hoist_count;) {
+			const c4ptr R = hbox.offset_floats((unsigned int)j * 8u);
+			const float4 a0 = R[0], a1 = R[1];
+			const int second = __float_as_int(a1.z);         // a partner with the same box follows (rt_lbvh.hip k_hoist), or -1
+			RT_PROF(wp, WP_INBOX);
+			if constexpr (COUNT) lc.box += lim >= 0.0f;
+			if (__builtin_amdgcn_ballot_w64(slab_hit_oct(a0, a1, inv, oi, lim_hi)) != 0) {
+				packet_leaf<COUNT>(hrec.offset_floats((unsigned int)j * (RT_AOS_F4 * 4u)), __float_as_int(a1.w), o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp);
+				if (second >= 0) packet_leaf<COUNT>(hrec.offset_floats((unsigned int)(j + 1) * (RT_AOS_F4 * 4u)), second, o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp);
+			}
+			j += second >= 0 ? 2 : 1;
+		}
 	}
 #ifdef RT_PROFILE
 	if (wp.g && __builtin_ctzll(__builtin_amdgcn_ballot_w64(true)) == (int)__lane_id()) {   // histogram of node steps per walk: counters 20..27
