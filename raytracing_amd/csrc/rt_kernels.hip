@@ -822,7 +822,8 @@ __device__ __forceinline__ Hit trace_brute(const DevScene& sc_arg, const float* 
 	float lim = fminf(ex + fabsf(ex) * 1e-4f, 1e9f);                     // 1e9: Source.cpp:278
 	const bool some_far = __builtin_amdgcn_ballot_w64(live && !near) != 0ull;      // (rays from beyond far_guard: rare, wave-uniform branch)
 	if (some_far && !near) { lim = 1e9f; inv = make3(0.f, 0.f, 0.f); oi = make3(0.f, 0.f, 0.f); }
-	if constexpr (KIND == RAY_SHADOW) lim = fminf(lim, __uint_as_float(__float_as_uint(dist) + 1u));   // first float > dist (Source.cpp:476)
+	// a shadow ray's limit is the first float > dist (Source.cpp:476); the exit bound could only repeat what that already says
+	if constexpr (KIND == RAY_SHADOW) lim = __uint_as_float(__float_as_uint(dist) + 1u);
 	lim = fminf(lim, 1e9f);
 	if (!live) lim = -1.0f;
 	const unsigned int lane_oct = (__float_as_uint(ds.x) >> 31) | ((__float_as_uint(ds.y) >> 31) << 1) | ((__float_as_uint(ds.z) >> 31) << 2);
@@ -854,7 +855,7 @@ __device__ __forceinline__ Hit trace_packet(const DevScene& sc_arg, vec3 o, vec3
 	if (__builtin_amdgcn_ballot_w64(live && !near) != 0ull) {          // rays from beyond far_guard: every box tests as hit for them
 		if (!near) { lim = 1e9f; inv = make3(0.f, 0.f, 0.f); oi = make3(0.f, 0.f, 0.f); }
 	}
-	if constexpr (KIND == RAY_SHADOW) lim = fminf(lim, __uint_as_float(__float_as_uint(dist) + 1u));
+	if constexpr (KIND == RAY_SHADOW) lim = __uint_as_float(__float_as_uint(dist) + 1u);   // (no exit bound: see trace_brute)
 	lim = fminf(lim, 1e9f);
 	const unsigned int lane_oct = (__float_as_uint(ds.x) >> 31) | ((__float_as_uint(ds.y) >> 31) << 1) | ((__float_as_uint(ds.z) >> 31) << 2);
 	unsigned long long todo = __builtin_amdgcn_ballot_w64(live);

@@ -65,7 +65,7 @@ __device__ __forceinline__ Hit cast_ray_lbvh(const DevScene& sc, int* lds_stack,
 	                             fmaxf(__builtin_fmaf(sc.bb_lo[1], s.inv.y, s.oi.y), __builtin_fmaf(sc.bb_hi[1], s.inv.y, s.oi.y))),
 	                       fmaxf(__builtin_fmaf(sc.bb_lo[2], s.inv.z, s.oi.z), __builtin_fmaf(sc.bb_hi[2], s.inv.z, s.oi.z)));
 	float lim = cull ? fminf(ex + fabsf(ex) * 1e-4f, 1e9f) : 1e9f;
-	if (shadow) lim = fminf(lim, __uint_as_float(__float_as_uint(dist) + 1u));          // Source.cpp:476
+	if (shadow) lim = __uint_as_float(__float_as_uint(dist) + 1u);                      // Source.cpp:476 (the exit bound has nothing to add: the lockstep kernel drops it)
 	lim = fminf(lim, 1e9f);
 	float lim_hi = lim + fabsf(lim) * RT_PREFILTER_REL;
 	if (!cull) { s.inv = make3(0.f, 0.f, 0.f); s.oi = make3(0.f, 0.f, 0.f); }           // every (non-empty) box tests as hit
