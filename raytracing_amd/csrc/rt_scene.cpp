@@ -168,9 +168,9 @@ float scene_box(const std::vector<float>& tris, float lo[3], float hi[3]) {
 //     three fma roundings of partial sums bounded by A (|w| + E)                      <= 5 u A (|w| + E)
 // with E = max(|p2 - p1|_1, |p3 - p1|_1).  11 u A (|w| + E) <= G |w|_1 + H for G = 16 u A, H = G E (both rounded up by
 // 2^-10) — no product may overflow or leave the normal range for this to hold, which the kernels make sure of by
-// trusting the filter only for 1e-20 < G |w|_1 + H < 1e20 (all partial results are then below 1e27, and what underflow
-// can add is 40 orders of magnitude below the threshold).  A degenerate triangle (n not finite) gets G = NaN:
-// never trusted.
+// trusting the filter only for G |w|_1 + H < 1e20 (all partial results are then below 1e27) and raising the threshold to
+// 1e-20 where it is smaller (what underflow can add is 20 orders of magnitude below that).  A degenerate triangle
+// (n not finite) and one whose G is outside [1e-30, 1e30] get G = NaN: never trusted.
 static void edge_filter_planes(const float* t, float* m0, float* m1, float* m2) {
 	const float* nrm = t + 3; const float* p1 = t + 6; const float* p2 = t + 9; const float* p3 = t + 12;
 	const float* e[3] = { t + 15, t + 18, t + 21 };
@@ -201,7 +201,9 @@ static void edge_filter_planes(const float* t, float* m0, float* m1, float* m2) 
 	m1[3] = (float)c1;
 	m2[3] = (float)(H * up);
 	// a filter that cannot be trusted for this triangle: G = NaN sends every lane to the reference's arithmetic
-	bool ok = G - G == 0.0 && H - H == 0.0 && c1 - c1 == 0.0 && fabs(c1) < 1e30;
+	// (G below 1e-30 — edges shorter than ~1e-24 — is switched off too: as a binary32 near or below the normal range it would no longer
+	// be the bound to 2^-24, and with it the roundings of denormal M components, at most 2^-150 |w|, are always far inside G |w|_1)
+	bool ok = G - G == 0.0 && H - H == 0.0 && c1 - c1 == 0.0 && fabs(c1) < 1e30 && G >= 1e-30 && G < 1e30;
 	for (int k = 0; k < 3 && ok; k++) for (int c = 0; c < 3; c++) if (!(fabs(M[k][c]) < 1e30)) ok = false;
 	if (!ok) m0[3] = __builtin_nanf("");
 }
