@@ -208,6 +208,16 @@ static void edge_filter_planes(const float* t, float* m0, float* m1, float* m2) 
 	if (!ok) m0[3] = __builtin_nanf("");
 }
 
+} // namespace rt
+
+// Test hook (not part of include/rt355.h): the twelve filter constants of one 28-float triangle record — M0.xyz G | M1.xyz c1 |
+// M2.xyz H — so that the CPU suite can hold the bound against exact rational arithmetic without a GPU.
+extern "C" void rt_internal_edge_filter_planes(const float* tri28, float* out12) {
+	rt::edge_filter_planes(tri28, out12, out12 + 4, out12 + 8);
+}
+
+namespace rt {
+
 PlaneLayout flatten_planes(const std::vector<float>& tris, int stride, float pad, bool with_octant_records, std::vector<float>& out) {
 	const int n = (int)(tris.size() / RT_TRI_FLOATS);
 	const float inf = __builtin_huge_valf();
