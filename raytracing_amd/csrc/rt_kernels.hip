@@ -504,13 +504,21 @@ template <bool COUNT>
 __device__ __forceinline__ void hoisted_tests(const DevScene& sc, vec3 o, vec3 d, vec3 inv, vec3 oi, int skip, bool live, bool first_only,
                                               Hit& h, float& lim, float& lim_hi, LaneCounters& lc, WaveProf& wp) {
 	c4ptr T = c4ptr_of(sc.hoist);
-	c4ptr B = T.offset_floats((unsigned int)sc.hoist_count * (RT_AOS_F4 * 4u));                           // octant 0: near = lo, far = hi
+	// The lanes of a tile nearly always point into one octant: then that octant's copy of the boxes (near and far faces
+	// known per axis, as the packet walk reads them) saves the per-axis min/max of the general slab test; a wave of mixed
+	// octants reads the copy of octant 0 (near = lo, far = hi) with the general test.
+	const unsigned int lane_oct = (__float_as_uint(inv.x) >> 31) | ((__float_as_uint(inv.y) >> 31) << 1) | ((__float_as_uint(inv.z) >> 31) << 2);
+	const unsigned long long lv = __builtin_amdgcn_ballot_w64(live);
+	const unsigned int oct = __builtin_amdgcn_readlane(lane_oct, lv ? __builtin_ctzll(lv) : 0);
+	const bool one_octant = __builtin_amdgcn_ballot_w64(live && lane_oct != oct) == 0ull;
+	c4ptr B = T.offset_floats((unsigned int)sc.hoist_count * (RT_AOS_F4 * 4u) + (one_octant ? oct : 0u) * (unsigned int)sc.hoist_count * 8u);
 	for (int j = 0; j < sc.hoist_count;) {
 		const float4 b0 = B[0], b1 = B[1];
 		const int second = __float_as_int(b1.z);             // a partner with the same box follows (rt_lbvh.hip k_hoist), or -1
 		const int members = second >= 0 ? 2 : 1;
 		if constexpr (COUNT) lc.box += live;
-		const bool meets = __builtin_amdgcn_ballot_w64(live && slab_hit(b0, make_float4(b0.w, b1.x, b1.y, 0.f), inv, oi, lim_hi)) != 0;
+		const bool meets = one_octant ? __builtin_amdgcn_ballot_w64(live && slab_hit_oct(b0, b1, inv, oi, lim_hi)) != 0
+		                              : __builtin_amdgcn_ballot_w64(live && slab_hit(b0, make_float4(b0.w, b1.x, b1.y, 0.f), inv, oi, lim_hi)) != 0;
 		for (int m = 0; m < members && meets; m++) {
 			RT_PROF(wp, WP_TRI);
 			const c4ptr Tm = T.offset_floats((RT_AOS_F4 * 4) * m);
