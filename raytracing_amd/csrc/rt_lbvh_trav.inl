@@ -111,6 +111,7 @@ __device__ __forceinline__ Hit cast_ray_lbvh(const DevScene& sc, int* lds_stack,
 	// a leaf trip serves many lanes.  The order in which a ray meets its triangles does not matter
 	// (see the header), only that all of them are met before the ray finishes.
 	int pend = SENT;
+	const bool pos_x = s.inv.x >= 0.0f, pos_y = s.inv.y >= 0.0f, pos_z = s.inv.z >= 0.0f;
 	while (node != SENT || pend != SENT) {
 		const bool inner = (unsigned int)node < (unsigned int)SENT;
 #ifdef RT_PROFILE
@@ -146,9 +147,11 @@ __device__ __forceinline__ Hit cast_ray_lbvh(const DevScene& sc, int* lds_stack,
 			int ref[4] = { (int)w1.x, (int)w1.y, (int)w1.z, (int)w1.w };
 			// A's sign is the ray direction's: the near slab plane is `lo` when it is positive, `hi` otherwise.
 			// Picking the words once per node replaces the per-child min/max of the two slab distances.
-			const unsigned int nx = Ax >= 0.0f ? w2.x : w2.w, fx = Ax >= 0.0f ? w2.w : w2.x;
-			const unsigned int ny = Ay >= 0.0f ? w2.y : w3.x, fy = Ay >= 0.0f ? w3.x : w2.y;
-			const unsigned int nz = Az >= 0.0f ? w2.z : w3.y, fz = Az >= 0.0f ? w3.y : w2.z;
+			// (asked of inv, not of A = 2^e inv: the same sign whenever it matters — with 2^e = 0 both choices give t = B — and a
+			// condition that does not change along the ray, so its three compares leave the loop)
+			const unsigned int nx = pos_x ? w2.x : w2.w, fx = pos_x ? w2.w : w2.x;
+			const unsigned int ny = pos_y ? w2.y : w3.x, fy = pos_y ? w3.x : w2.y;
+			const unsigned int nz = pos_z ? w2.z : w3.y, fz = pos_z ? w3.y : w2.z;
 #define RT_QB(word, c) ((float)(((word) >> (8 * (c))) & 0xffu))      /* v_cvt_f32_ubyteN */
 			const float lim_q = __builtin_canonicalizef(lim_hi);           // once per node instead of once per child (fminf quiets its operands)
 #pragma unroll
