@@ -188,9 +188,10 @@ __global__ void __launch_bounds__(256) k_refit(const float4* __restrict__ planes
 //    seven: child boxes are stored as 8-bit offsets from the node's own corner p in units of
 //    2^e per axis, rounded outward (lo down, hi up) — a quantised box contains the padded box it
 //    stands for, and boxes only ever skip work.  Layout (4 x 16 B):
-//      w0 = (p.x, p.y, p.z, ex | ey << 8 | ez << 16)      biased exponents: scale_a = bits(e_a << 23)
+//      w0 = (p.x, p.y, p.z, scale.x)      scale_a = 2^e_a as a binary32 (round 1 packed three exponent bytes into w0.w:
+//                                         six integer instructions per node to unpack, and w3 had the room)
 //      w1 = the 4 child references (RT_BVH4_EMPTY for an unused slot)
-//      w2 = (lo.x of children 0..3 as 4 bytes, lo.y, lo.z, hi.x)     w3 = (hi.y, hi.z, 0, 0)
+//      w2 = (lo.x of children 0..3 as 4 bytes, lo.y, lo.z, hi.x)     w3 = (hi.y, hi.z, scale.y, scale.z)
 __device__ __forceinline__ unsigned int quant_axis(const float lo[4], const float hi[4], int cnt, float& p, unsigned int& qlo, unsigned int& qhi) {
 	float mn = lo[0], mx = hi[0];
 	for (int c = 1; c < cnt; c++) { mn = fminf(mn, lo[c]); mx = fmaxf(mx, hi[c]); }
@@ -269,10 +270,10 @@ __global__ void __launch_bounds__(256) k_collapse4(const float4* __restrict__ no
 	unsigned int ql[3], qh[3], eb[3];
 	for (int k = 0; k < 3; k++) eb[k] = quant_axis(lo[k], hi[k], cnt, p[k], ql[k], qh[k]);
 	uint4* o = out + (size_t)i * 4;
-	o[0] = make_uint4(__float_as_uint(p[0]), __float_as_uint(p[1]), __float_as_uint(p[2]), eb[0] | (eb[1] << 8) | (eb[2] << 16));
+	o[0] = make_uint4(__float_as_uint(p[0]), __float_as_uint(p[1]), __float_as_uint(p[2]), eb[0] << 23);
 	o[1] = make_uint4((unsigned int)ref[0], (unsigned int)ref[1], (unsigned int)ref[2], (unsigned int)ref[3]);
 	o[2] = make_uint4(ql[0], ql[1], ql[2], qh[0]);
-	o[3] = make_uint4(qh[1], qh[2], 0u, 0u);
+	o[3] = make_uint4(qh[1], qh[2], eb[1] << 23, eb[2] << 23);
 }
 
 __device__ __forceinline__ void aos_record(const float4* __restrict__ planes, int stride, int i, float4* __restrict__ o) {

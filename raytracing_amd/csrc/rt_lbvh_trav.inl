@@ -138,11 +138,11 @@ __device__ __forceinline__ Hit cast_ray_lbvh(const DevScene& sc, int* lds_stack,
 			// (uniform base + 32-bit byte offset: the load's own addressing form, no 64-bit address arithmetic per lane)
 			const char* nd = (const char*)sc.bvh4 + (unsigned int)node * 64u;
 			const uint4 w0 = *(const uint4*)nd, w1 = *(const uint4*)(nd + 16), w2 = *(const uint4*)(nd + 32);
-			const uint2 w3 = *(const uint2*)(nd + 48);
+			const uint4 w3 = *(const uint4*)(nd + 48);
 			// per axis: t(q) = (p + q * 2^e) * inv + oi = q * A + B
-			const float Ax = __uint_as_float((w0.w & 0xffu) << 23) * s.inv.x, Bx = __builtin_fmaf(__uint_as_float(w0.x), s.inv.x, s.oi.x);
-			const float Ay = __uint_as_float(((w0.w >> 8) & 0xffu) << 23) * s.inv.y, By = __builtin_fmaf(__uint_as_float(w0.y), s.inv.y, s.oi.y);
-			const float Az = __uint_as_float(((w0.w >> 16) & 0xffu) << 23) * s.inv.z, Bz = __builtin_fmaf(__uint_as_float(w0.z), s.inv.z, s.oi.z);
+			const float Ax = __uint_as_float(w0.w) * s.inv.x, Bx = __builtin_fmaf(__uint_as_float(w0.x), s.inv.x, s.oi.x);
+			const float Ay = __uint_as_float(w3.z) * s.inv.y, By = __builtin_fmaf(__uint_as_float(w0.y), s.inv.y, s.oi.y);
+			const float Az = __uint_as_float(w3.w) * s.inv.z, Bz = __builtin_fmaf(__uint_as_float(w0.z), s.inv.z, s.oi.z);
 			float key[4];
 			int ref[4] = { (int)w1.x, (int)w1.y, (int)w1.z, (int)w1.w };
 			// A's sign is the ray direction's: the near slab plane is `lo` when it is positive, `hi` otherwise.
