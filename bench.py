@@ -220,6 +220,27 @@ class Workload:
         self.scene.close()
 
 
+_DEVICE = {}
+
+
+def device_info(torch, dev):
+    """What the box says it is (record CU count and clock next to the peak used): the FP32 VALU peak recomputed
+    from them, CUs x 256 FLOP/clk x the reported engine clock, is informative; `peak` stays the guide's 157.3."""
+    if not _DEVICE:
+        try:
+            p = torch.cuda.get_device_properties(dev)
+            import ctypes
+            from raytracing_amd import api as _api
+            cus, clk = ctypes.c_int(0), ctypes.c_int(0)
+            khz = clk.value if _api.lib().rt_device_props(int(dev), ctypes.byref(cus), ctypes.byref(clk)) == 0 else 0
+            _DEVICE.update({"name": p.name, "gcn_arch": getattr(p, "gcnArchName", None), "compute_units": p.multi_processor_count,
+                            "clock_mhz": khz / 1e3 if khz else None,
+                            "fp32_valu_peak_from_these": p.multi_processor_count * 256 * khz * 1e3 / 1e12 if khz else None})
+        except Exception as e:                       # (informative only)
+            _DEVICE.update({"error": str(e)})
+    return dict(_DEVICE)
+
+
 def roofline_of(flops_per_launch, kernel_ms, fpl, launches, workload):
     achieved = flops_per_launch / (kernel_ms * 1e-3) / 1e12
     pmc = read_profile_json("traffic.json").get(workload)
@@ -365,6 +386,7 @@ def run_frames_mode(args, api, torch, dist, rank, world, dev, on_gpu, name):
                                  "over the %d consecutive poses from ((s*N + r)*%d) mod 64" % (fpl, fpl),
                        "rays_per_frame_mean": total_rays / frames_total, "parallelism": "frames x%d" % world},
             "roofline": roofline_of(my_flops / args.steps, kernel_ms, fpl, args.steps, name),
+            "device": device_info(torch, dev),
         }
         if world == 1 and not args.no_configs:
             out["hand_off"] = hand_off(api, torch, w)
@@ -502,6 +524,7 @@ def run_tile_mode(args, api, torch, dist, rank, world, dev, on_gpu, name):
                                   if fmt == "rgba8" else "binary32 RGB (the reference's `data`)"),
                        "exchange": "one non-blocking gather of the compact %s shards to rank 0 per frame (%s; shards padded to a common size), two shard buffers per rank" % (fmt, args.backend)},
             "roofline": roofline_of(flops / args.steps * share, kernel_ms, 1, args.steps, name),
+            "device": device_info(torch, dev),
             "exchange": {"format": fmt, "kernel_ms_rank0": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
                          "non_render_ms_per_frame": wall / args.steps * 1e3 - kernel_ms_max,
                          "shard_MB": rows * W * bytes_px[fmt] / 1e6,

@@ -273,6 +273,9 @@ int rt_cast_rays_noalloc(rt_scene* s, int n_rays, const float* rays7, float* out
 /* ---- misc ---------------------------------------------------------------------------------- */
 
 int         rt_device_count(void);
+/* What the device says it is: compute units and engine clock (kHz), for the roofline lines of bench.py (SURVEY 8d asks for
+ * them next to the peak that is used).  No counterpart in the reference.  Either pointer may be NULL. */
+int         rt_device_props(int device, int* compute_units, int* clock_khz);
 
 /* Tuning knob of one scene: 8x8 pixel tiles each wavefront walks; 0 = the launcher's rule, at
  * most RT_TILES_PER_WAVE_MAX.  Pixels do not depend on it. */

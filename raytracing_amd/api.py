@@ -43,7 +43,7 @@ SYMBOLS = (
     "rt_camera_translate", "rt_camera_frame_time", "rt_camera_step", "rt_camera_path", "rt_render", "rt_render_device",
     "rt_render_frames_device", "rt_render_tiles_device", "rt_shard_rows", "rt_render_stats", "rt_render_multi", "rt_cast_rays",
     "rt_render_async", "rt_render_wait", "rt_frame_alloc", "rt_frame_free", "rt_cast_rays_noalloc",
-    "rt_device_count", "rt_scene_set_tiles_per_wave", "rt_scene_set_traversal", "rt_scene_set_kernel", "rt_scene_set_build", "rt_scene_traversal", "rt_last_error", "rt_version",
+    "rt_device_count", "rt_device_props", "rt_scene_set_tiles_per_wave", "rt_scene_set_traversal", "rt_scene_set_kernel", "rt_scene_set_build", "rt_scene_traversal", "rt_last_error", "rt_version",
 )
 
 
@@ -149,6 +149,7 @@ def lib():
     L.rt_render_multi.argtypes = [vp, C.POINTER(ci), ci, _fp, _fp, ci, ci, ci, ci, ci, _fp]
     L.rt_cast_rays.argtypes = [vp, ci, _fp, _fp]
     L.rt_device_count.argtypes = []
+    L.rt_device_props.argtypes = [ci, C.POINTER(ci), C.POINTER(ci)]
     L.rt_scene_set_tiles_per_wave.argtypes = [vp, ci]
     L.rt_scene_set_traversal.argtypes = [vp, ci]
     L.rt_scene_set_kernel.argtypes = [vp, ci]

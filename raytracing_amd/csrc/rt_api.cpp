@@ -218,6 +218,15 @@ int rt_device_count(void) {
 	return n;
 }
 
+int rt_device_props(int device, int* compute_units, int* clock_khz) {
+	hipDeviceProp_t p;
+	hipError_t e = hipGetDeviceProperties(&p, device);
+	if (e != hipSuccess) { (void)hipGetLastError(); set_error("rt_device_props: device %d: %s", device, hipGetErrorString(e)); return RT_ERR_DEVICE; }
+	if (compute_units) *compute_units = p.multiProcessorCount;
+	if (clock_khz) *clock_khz = p.clockRate;
+	return RT_OK;
+}
+
 const char* rt_last_error(void) { return g_err; }
 const char* rt_version(void) { return "rt355 0.1 (gfx950)"; }
 

@@ -102,3 +102,13 @@ def test_bench_row_tile_mode_two_ranks_on_one_gpu():
     assert d["exchange_other_format"]["format"] == "f32" and d["exchange_other_format"]["shard_MB"] > 190
     assert d["roofline"]["frac"] > 0 and d["roofline"]["kernel_ms"] > 0
     assert d["single_gpu"]["ms_per_frame"] > 0 and d["value"] > 0
+
+
+def test_device_props_are_what_the_roofline_assumes():
+    """rt_device_props: the compute units and engine clock bench.py records next to the FP32 VALU peak it uses."""
+    import ctypes as C
+    cus, khz = C.c_int(0), C.c_int(0)
+    assert api.lib().rt_device_props(0, C.byref(cus), C.byref(khz)) == 0
+    assert cus.value > 0 and khz.value > 0
+    assert api.lib().rt_device_props(0, None, None) == 0
+    assert api.lib().rt_device_props(1 << 20, C.byref(cus), C.byref(khz)) != 0
