@@ -1,16 +1,17 @@
 #!/bin/bash
-# tools/profile.sh <round-tag> — run on the GPU box (gpurun).  For the headline workload (room800) and the
-# tree workloads (spheres800, spheres4k) it collects, each in a run of its own:
+# tools/profile.sh <round-tag> ["<workloads>"] — run on the GPU box (gpurun).  For the headline workload (room800) and the
+# tree workloads (spheres800, spheres4k) — or the bench.py workloads named in the second argument — it collects, each in a run of its own:
 #   (1) rocprofv3 --kernel-trace --stats of the bench command            -> <tag>_<w>_kernel_stats.csv
 #   (2) HBM traffic: FETCH_SIZE and WRITE_SIZE in separate --pmc passes   -> traffic.json (bytes per launch)
 #   (3) SQ instruction and wait counters                                  -> <tag>_<w>_pmc.json
 #   (4) the VALU instruction mix (two passes)                             -> issued.json (issued VALU TFLOP/s)
 # Summaries go to gpurun_out/profiles_<tag>/; copy what should be judged into profiles/.
 tag=${1:-r02}
+workloads=${2:-"room800 spheres800 spheres4k"}
 out=gpurun_out/profiles_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-for w in room800 spheres800 spheres4k; do
+for w in $workloads; do
   args="--steps 8 --warmup 2 --no-cpu --no-configs --workload $w"
   # (the kernel trace runs the default step counts, so that its average is over launches at steady clocks like bench.py's own)
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_$w -o $w -- python3 bench.py --steps 20 --warmup 5 --no-cpu --no-configs --workload $w > $out/${tag}_${w}_bench_under_rocprof.json 2> $out/trace_$w.err || exit 1
@@ -25,11 +26,11 @@ for w in room800 spheres800 spheres4k; do
     timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d $out/pmc_${w}_$i -o p -- python3 bench.py $args > $out/pmc_${w}_$i.json 2> $out/pmc_${w}_$i.err || exit 1
   done
 done
-python3 - $out $tag <<'PY'
+python3 - $out $tag $workloads <<'PY'
 import csv, sys, json, collections, glob, os
 out, tag = sys.argv[1], sys.argv[2]
 traffic, issued = {}, {}
-for w in ("room800", "spheres800", "spheres4k"):
+for w in sys.argv[3:]:
     # the dominant kernel of the run: the render kernel with the largest total time in the kernel trace
     # (room800: render_lockstep_kernel<0>; the tree scenes: <2> walked per lane or <3> by packets, as the launcher chose)
     rows = [r for r in csv.DictReader(open(os.path.join(out, "%s_%s_kernel_stats.csv" % (tag, w)))) if "render_lockstep_kernel" in r["Name"]]
@@ -71,4 +72,4 @@ for w in ("room800", "spheres800", "spheres4k"):
 json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 json.dump(issued, open(os.path.join(out, "issued.json"), "w"), indent=1)
 PY
-for w in room800 spheres800 spheres4k; do cat $out/${tag}_${w}_kernel_stats.csv; done
+for w in $workloads; do cat $out/${tag}_${w}_kernel_stats.csv; done
