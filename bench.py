@@ -61,6 +61,8 @@ WORKLOADS = {
     "sweep8k_spheres": (lambda s: s.spheres(20, 4, 7680, 4320), "lbvh", "102412 triangles 7680x4320, 64-pose camera path, LBVH", 8),
 }
 
+SPHERE_SIZES = {"spheres800": (800, 800), "spheres4k": (3840, 2160), "sweep8k_spheres": (7680, 4320)}
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -74,7 +76,9 @@ def parse():
     ap.add_argument("--size", type=int, nargs=2, default=None, help="override the workload's frame size (experiments)")
     ap.add_argument("--traversal", default="auto", choices=["auto", "per-lane", "packet"])
     ap.add_argument("--kernel", default="auto", choices=["auto", "state-machine", "lockstep"], help="form of the brute-force render kernel (rt_scene_set_kernel)")
-    ap.add_argument("--build", default="sah", choices=["fast", "sah"], help="how LBVH commits build their tree (rt_scene_set_build)")
+    ap.add_argument("--build", default="ploc", choices=["ploc", "fast", "sah"],
+                    help="how LBVH commits build their tree (rt_scene_set_build): ploc = Morton sort + locally-ordered clustering on the GPU (default), "
+                         "fast = Morton sort + Karras on the GPU, sah = binned SAH on host threads")
     ap.add_argument("--exchange", default="rgba8", choices=["rgba8", "f32"],
                     help="pixel format of the frames the row-tile mode renders and gathers (RT_OUT_RGBA8 or binary32 RGB)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -139,12 +143,21 @@ def cpu_threaded(desc, threads):
 class Workload:
     """One committed scene + its camera path + pre-marshalled launch arguments."""
 
-    def __init__(self, api, torch, name, dev, args, frames_per_launch=0):
+    _descs = {}     # scene descriptions by workload (102 412 triangles take seconds to list in Python; several configs share them)
+
+    def __init__(self, api, torch, name, dev, args, frames_per_launch=0, build=None):
         from raytracing_amd import scenes
         import ctypes as C
-        build, accel_name, label, fpl = WORKLOADS[name]
+        make, accel_name, label, fpl = WORKLOADS[name]
         self.api, self.torch, self.C, self.name, self.dev = api, torch, C, name, dev
-        desc = build(scenes)
+        if name not in Workload._descs:
+            if name in SPHERE_SIZES:       # one list of 102 412 triangles for all its frame sizes
+                if "spheres" not in Workload._descs:
+                    Workload._descs["spheres"] = make(scenes)
+                Workload._descs[name] = Workload._descs["spheres"].with_size(*SPHERE_SIZES[name])
+            else:
+                Workload._descs[name] = make(scenes)
+        desc = Workload._descs[name]
         if args.size:
             desc = desc.with_size(args.size[0], args.size[1])
             label += " [size overridden to %dx%d]" % tuple(args.size)
@@ -154,11 +167,19 @@ class Workload:
         self.scene = api.Scene.from_desc(desc)
         self.scene.set_traversal({"auto": api.TRAVERSAL_AUTO, "per-lane": api.TRAVERSAL_PER_LANE, "packet": api.TRAVERSAL_PACKET}[args.traversal])
         self.scene.set_kernel({"auto": api.KERNEL_AUTO, "state-machine": api.KERNEL_STATE_MACHINE, "lockstep": api.KERNEL_LOCKSTEP}[args.kernel])
-        self.scene.set_build({"fast": api.BUILD_FAST, "sah": api.BUILD_SAH}[args.build])
-        self.build = args.build if accel_name == "lbvh" else None
+        kinds = {"fast": api.BUILD_FAST, "sah": api.BUILD_SAH, "ploc": api.BUILD_PLOC}
+        self.scene.set_build(kinds[build or args.build])
+        self.build = None
         if args.tiles_per_wave:
             self.scene.set_tiles_per_wave(args.tiles_per_wave)
         self.scene.commit(dev, api.ACCEL_LBVH if accel_name == "lbvh" else api.ACCEL_BRUTE)
+        if accel_name == "lbvh":
+            # what REALLY built the tree (a clustered build that cannot finish falls back to Karras'), and the build time of a
+            # second commit: the first one in a process also loads the build kernels' code objects
+            self.build_ms_first = self.scene.build_ms(dev)
+            self.scene.commit(dev, api.ACCEL_LBVH)
+            self.build_ms = self.scene.build_ms(dev)
+            self.build = {v: k for k, v in kinds.items()}[self.scene.build_kind(dev)]
         self.cams, self.trans = api.camera_sweep(N_POSES, desc.cam_pos, desc.cam_rot)     # (64,3), (64,16): rt_camera_path
         self.rays_of, self.flops_of = {}, {}
         self.fb = None
@@ -253,9 +274,9 @@ def roofline_of(flops_per_launch, kernel_ms, fpl, launches, workload):
                     "the kernel really executes per second (PMC pass under profiles/), secondary"}
 
 
-def side_config(api, torch, name, dev, args, launches=6):
+def side_config(api, torch, name, dev, args, launches=6, build=None):
     """One of the other BASELINE configs, measured on its own: `launches` timed launches after two warm-up launches."""
-    w = Workload(api, torch, name, dev, args)
+    w = Workload(api, torch, name, dev, args, build=build)
     try:
         batches = [w.batch(s) for s in range(launches)]
         w.count([f for b in batches for f in b])
@@ -273,7 +294,9 @@ def side_config(api, torch, name, dev, args, launches=6):
                "flops_per_ray": flops / rays}
         if w.accel_name == "lbvh":
             out["build"] = w.build
-            out["build_ms"] = w.scene.build_ms(dev)
+            out["build_where"] = "host threads (topology) + GPU (boxes, records)" if w.build == "sah" else "GPU"
+            out["build_ms"] = w.build_ms
+            out["build_ms_first_commit"] = w.build_ms_first
             out["bvh_depth"] = list(w.scene.bvh_depth(dev))
         return out
     finally:
@@ -395,8 +418,10 @@ def run_frames_mode(args, api, torch, dist, rank, world, dev, on_gpu, name):
     torch.cuda.empty_cache()
     if rank == 0 and world == 1:
         if not args.no_configs:
-            out["configs"] = [side_config(api, torch, n, dev, args) for n in
-                              ("stock800", "mirrors4k", "spheres800", "spheres4k", "sweep8k", "sweep8k_spheres") if n != name]
+            # (config 4 through the tree of every build: the GPU-built ones are north_star's, the host's SAH tree is the yardstick)
+            out["configs"] = [side_config(api, torch, n, dev, args, build=b) for n, b in
+                              (("stock800", None), ("mirrors4k", None), ("spheres800", None), ("spheres800", "fast"), ("spheres800", "sah"),
+                               ("spheres4k", None), ("spheres4k", "fast"), ("spheres4k", "sah"), ("sweep8k", None), ("sweep8k_spheres", None)) if n != name]
         if not args.no_cpu:
             cb = cpu_baseline(w_desc, args.cpu_seconds)
             out["cpu_baseline"] = cb

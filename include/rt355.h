@@ -290,15 +290,21 @@ int         rt_scene_set_tiles_per_wave(rt_scene* s, int tiles);
 int         rt_scene_set_kernel(rt_scene* s, int kind);
 /* Tuning knob of one scene: how the tree of an RT_ACCEL_LBVH commit is built (takes effect at the next
  * rt_scene_commit; committed trees of the scene become stale).  Pixels do not depend on it.
- * SAH (the default): the topology by a binned surface-area heuristic on host threads, boxes and the
- * derived records on the GPU; about 15 ms per 100k triangles on 16 cores, for a tree rays cross in
- * fewer nodes (100k-triangle scene: 14 % less time per frame walked per lane, 8 % by packets) — a
- * scene committed once and rendered for many frames, which is the reference's use (Src:815-880 builds the
- * scene once in main).  FAST: Morton codes, radix sort and Karras' construction on the GPU, half a
- * millisecond per 100k triangles — for scenes that are re-committed every few frames. */
+ * PLOC (the default): everything on the GPU — Morton codes and radix sort, then parallel locally-ordered
+ * clustering over that order (each cluster merges with the neighbour, up to 8 places away, whose union with it has
+ * the smallest surface area; Meister & Bittner 2018), boxes made on the way up.  A tree of binned-SAH quality (sum
+ * of child-box areas over the root's, 102 412 triangles: 8.83; SAH 8.73; FAST 10.70) in about a millisecond.
+ * FAST: Morton codes, radix sort and Karras' construction on the GPU, half a millisecond per 100k triangles; also
+ * what a PLOC commit falls back to when clustering cannot finish (areas that overflow, a chain deeper than 63).
+ * SAH: the topology by a binned surface-area heuristic on host threads, boxes and the derived records on the GPU;
+ * about 15 ms per 100k triangles on 16 cores (round 2's default, kept for comparison). */
 #define RT_BUILD_FAST 0
 #define RT_BUILD_SAH  1
+#define RT_BUILD_PLOC 2
 int         rt_scene_set_build(rt_scene* s, int quality);
+/* What really built the tree of the last LBVH commit on `device`: RT_BUILD_PLOC, _SAH or _FAST (a PLOC commit that
+ * fell back reports FAST); RT_ERR_STATE for a brute-force commit.  No counterpart in the reference. */
+int         rt_scene_build_kind(const rt_scene* s, int device);
 /* Tuning knob of one scene: how its LBVH is traversed.  RT_TRAVERSAL_AUTO lets each launch choose
  * by the coherence of an 8x8 tile of rays against the scene's triangles; both give
  * the reference's bits.  A preference: a tree too deep for the per-lane stack (rt_scene_bvh_depth)

@@ -23,7 +23,7 @@ RT_OK = 0
 ACCEL_AUTO, ACCEL_BRUTE, ACCEL_LBVH = 0, 1, 2
 TRAVERSAL_AUTO, TRAVERSAL_PER_LANE, TRAVERSAL_PACKET = 0, 1, 2
 KERNEL_AUTO, KERNEL_STATE_MACHINE, KERNEL_LOCKSTEP = 0, 1, 2
-BUILD_FAST, BUILD_SAH = 0, 1
+BUILD_FAST, BUILD_SAH, BUILD_PLOC = 0, 1, 2
 STRICT = 0            # RT_RENDER_STRICT: the only render mode (bit-identical frames)
 OUT_RGBA8 = 0x100     # RT_OUT_RGBA8: the output buffer takes packed 8-bit pixels instead of three floats
 SHADE_GLSL = 0x200    # RT_SHADE_GLSL: the colour arithmetic of the reference's compute shader (Compute.shader:181-219, 330)
@@ -43,7 +43,7 @@ SYMBOLS = (
     "rt_camera_translate", "rt_camera_frame_time", "rt_camera_step", "rt_camera_path", "rt_render", "rt_render_device",
     "rt_render_frames_device", "rt_render_tiles_device", "rt_shard_rows", "rt_render_stats", "rt_render_multi", "rt_cast_rays",
     "rt_render_async", "rt_render_wait", "rt_frame_alloc", "rt_frame_free", "rt_cast_rays_noalloc",
-    "rt_device_count", "rt_device_props", "rt_scene_set_tiles_per_wave", "rt_scene_set_traversal", "rt_scene_set_kernel", "rt_scene_set_build", "rt_scene_traversal", "rt_last_error", "rt_version",
+    "rt_device_count", "rt_device_props", "rt_scene_set_tiles_per_wave", "rt_scene_set_traversal", "rt_scene_set_kernel", "rt_scene_set_build", "rt_scene_build_kind", "rt_scene_traversal", "rt_last_error", "rt_version",
 )
 
 
@@ -154,6 +154,7 @@ def lib():
     L.rt_scene_set_traversal.argtypes = [vp, ci]
     L.rt_scene_set_kernel.argtypes = [vp, ci]
     L.rt_scene_set_build.argtypes = [vp, ci]
+    L.rt_scene_build_kind.argtypes = [vp, ci]
     L.rt_scene_bvh_depth.argtypes = [vp, ci, C.POINTER(ci), C.POINTER(ci)]
     L.rt_render_async.argtypes = [vp, _fp, _fp, ci, ci, ci, ci, vp]
     L.rt_render_wait.argtypes = [vp, ci]
@@ -424,10 +425,15 @@ class Scene:
         return self
 
     def set_build(self, quality: int) -> "Scene":
-        """How the tree of the next LBVH commit is built: BUILD_FAST (Morton/Karras on the GPU) or BUILD_SAH
-        (binned surface-area heuristic on the host; rt_scene_set_build)."""
+        """How the tree of the next LBVH commit is built (rt_scene_set_build): BUILD_PLOC (the default: Morton sort +
+        locally-ordered clustering, all on the GPU), BUILD_FAST (Morton/Karras on the GPU) or BUILD_SAH (binned
+        surface-area heuristic on host threads)."""
         _check(lib().rt_scene_set_build(self._h, int(quality)))
         return self
+
+    def build_kind(self, device: int = 0) -> int:
+        """BUILD_* the tree of the last LBVH commit was really built by (a PLOC commit that fell back reports BUILD_FAST)."""
+        return _check(lib().rt_scene_build_kind(self._h, int(device)))
 
     def set_tiles_per_wave(self, tiles: int) -> "Scene":
         _check(lib().rt_scene_set_tiles_per_wave(self._h, int(tiles)))

@@ -261,12 +261,20 @@ int rt_scene_set_kernel(rt_scene* s, int kind) {
 
 int rt_scene_set_build(rt_scene* s, int quality) {
 	if (!s) { set_error("rt_scene_set_build: NULL scene"); return RT_ERR_INVALID; }
-	if (quality != RT_BUILD_FAST && quality != RT_BUILD_SAH) { set_error("rt_scene_set_build: unknown quality %d", quality); return RT_ERR_INVALID; }
+	if (quality != RT_BUILD_FAST && quality != RT_BUILD_SAH && quality != RT_BUILD_PLOC) { set_error("rt_scene_set_build: unknown quality %d", quality); return RT_ERR_INVALID; }
 	if (s->build != quality) {
 		s->build = quality;
 		for (auto& kv : s->dev) if (kv.second.accel == RT_ACCEL_LBVH) kv.second.valid = false;      // trees are rebuilt at the next commit
 	}
 	return RT_OK;
+}
+
+int rt_scene_build_kind(const rt_scene* s, int device) {
+	if (!s) { set_error("rt_scene_build_kind: NULL scene"); return RT_ERR_INVALID; }
+	auto it = s->dev.find(device);
+	if (it == s->dev.end() || !it->second.valid) { set_error("rt_scene_build_kind: not committed on device %d", device); return RT_ERR_STATE; }
+	if (it->second.accel != RT_ACCEL_LBVH) { set_error("rt_scene_build_kind: device %d holds a brute-force commit", device); return RT_ERR_STATE; }
+	return it->second.built_by;
 }
 
 int rt_scene_bvh_depth(const rt_scene* s, int device, int* binary_depth, int* wide_depth) {

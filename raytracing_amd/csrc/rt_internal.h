@@ -148,6 +148,7 @@ struct DeviceState {
 	int bvh_root = 0;
 	int stride = 0;
 	float build_ms = 0.f;
+	int built_by = -1;           // RT_BUILD_* the tree of this commit was really built by (PLOC falls back to FAST when it cannot finish)
 	float bb_lo[3] = { 0, 0, 0 }, bb_hi[3] = { 0, 0, 0 };
 	float far_guard = 0.f;
 	float pad = 0.f;
@@ -180,7 +181,7 @@ struct rt_scene {
 	int tiles_per_wave = 0;               // rt_scene_set_tiles_per_wave (0: the launcher's rule)
 	long long next_ticket = 0;            // rt_render_async
 	int kernel_kind = RT_KERNEL_AUTO;     // rt_scene_set_kernel
-	int build = RT_BUILD_SAH;             // rt_scene_set_build (takes effect at the next LBVH commit)
+	int build = RT_BUILD_PLOC;            // rt_scene_set_build (takes effect at the next LBVH commit)
 	int uv_w = -1, uv_h = -1;             // frame size the division-free u, v were last checked for (rt_api.cpp fill_frame)
 	bool uv_fast = false;
 };

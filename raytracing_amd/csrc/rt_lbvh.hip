@@ -389,6 +389,242 @@ __global__ void __launch_bounds__(64) k_hoist(const float4* __restrict__ planes,
 	}
 }
 
+// ---- RT_BUILD_PLOC: the tree by parallel locally-ordered clustering (Meister & Bittner 2018) ON the GPU ----
+// Bottom-up over the Morton order the radix sort leaves: every cluster (at first: every triangle's padded box)
+// looks RT_PLOC_R places to either side for the neighbour whose union with it has the smallest surface area; two
+// clusters that choose each other merge into a new inner node; the survivors are compacted in order and the search
+// repeats until one cluster — the root — is left.  The agglomeration sees the actual boxes, not the bits of a grid,
+// so the tree is of binned-SAH quality (102 412 triangles: sum of child-box areas over the root's 8.83, host SAH build
+// 8.73, Morton/Karras 10.70; scripts/ploc_proto.py is the CPU prototype these kernels follow) at GPU build speed.
+//   * Ties go to the lower index, so the globally closest pair always chooses each other: every pass merges at
+//     least one pair.  (A scene whose areas overflow to inf/NaN may stall; the pass budget then gives up and the
+//     commit falls back to the Morton/Karras build.)
+//   * A pass over more than RT_PLOC_TAIL clusters is two launches: k_ploc_search — a workgroup loads 256 consecutive
+//     clusters to LDS, finds the neighbour of the middle 240, decides for its own 224 (keep / lead a merge / merged
+//     away) and ranks them (wave ballots); k_ploc_merge — sums the ranks of the workgroups before it (no look-back
+//     spinning: the launch boundary is the grid barrier), writes the compacted clusters to the other buffer and the
+//     new nodes: both children's boxes and references, so no refit pass is needed.  Nodes are numbered from nt-2
+//     DOWN in merge order, so the last merge — the root — is node 0, where every consumer of the tree expects it.
+//   * From RT_PLOC_TAIL clusters on, ONE workgroup finishes the tree in LDS (k_ploc_tail): the last ~25 passes
+//     cost a barrier each instead of two launches.
+// Pass state (cluster count, merges so far, which buffer is current) lives on the device, one record per pass; the
+// host reads it back every few passes only to size the next launches.
+#ifndef RT_PLOC_R
+#define RT_PLOC_R 8
+#endif
+#define RT_PLOC_T 256
+#define RT_PLOC_C (RT_PLOC_T - 4 * RT_PLOC_R)
+#define RT_PLOC_TAIL 1024
+#define RT_PLOC_MAX_PASSES 384
+
+struct PlocState { int n, merges, cur, fail; };
+
+__device__ __forceinline__ float union_area(float4 alo, float4 ahi, float4 blo, float4 bhi) {
+	const float x = fmaxf(ahi.x, bhi.x) - fminf(alo.x, blo.x), y = fmaxf(ahi.y, bhi.y) - fminf(alo.y, blo.y), z = fmaxf(ahi.z, bhi.z) - fminf(alo.z, blo.z);
+	return x * y + y * z + z * x;
+}
+
+__device__ __forceinline__ void write_merged_node(float4* __restrict__ nodes, int node, float4 alo, float4 ahi, float4 blo, float4 bhi) {
+	float4* nd = nodes + (size_t)node * 4;
+	nd[0] = make_float4(alo.x, alo.y, alo.z, ahi.x);
+	nd[1] = make_float4(ahi.y, ahi.z, blo.x, blo.y);
+	nd[2] = make_float4(blo.z, bhi.x, bhi.y, bhi.z);
+	nd[3] = make_float4(alo.w, blo.w, 0.f, 0.f);                 // (the references travel in lo.w)
+}
+
+// leaves in Morton order -> the first cluster buffer: (lo.xyz, reference ~triangle), (hi.xyz, -)
+__global__ void __launch_bounds__(256) k_ploc_init(const float4* __restrict__ planes, int stride, int nt, const u64* __restrict__ keys,
+                                                  unsigned int index_mask, float pad, float4* __restrict__ lo, float4* __restrict__ hi,
+                                                  PlocState* __restrict__ state) {
+	const int p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p == 0) { PlocState s; s.n = nt; s.merges = 0; s.cur = 0; s.fail = 0; state[0] = s; }
+	if (p >= nt) return;
+	const int tri = (int)((unsigned int)keys[p] & index_mask);
+	float l[3], h[3];
+	tri_box_padded(planes, stride, tri, pad, l, h);
+	lo[p] = make_float4(l[0], l[1], l[2], __int_as_float(~tri));
+	hi[p] = make_float4(h[0], h[1], h[2], 0.f);
+}
+
+// kind of a cluster after the search: 0 stays, 1 leads a merge (the lower index of a mutual pair), 2 merged away
+__global__ void __launch_bounds__(RT_PLOC_T) k_ploc_search(const float4* __restrict__ lo0, const float4* __restrict__ hi0, const float4* __restrict__ lo1,
+                                                          const float4* __restrict__ hi1, const PlocState* __restrict__ state, int pass,
+                                                          int2* __restrict__ dec, int2* __restrict__ totals) {
+	const PlocState st = state[pass];
+	const int n = st.n;
+	const int base = (int)blockIdx.x * RT_PLOC_C;
+	if (n <= RT_PLOC_TAIL || base >= n || st.fail) return;
+	const float4* __restrict__ lo = st.cur ? lo1 : lo0;
+	const float4* __restrict__ hi = st.cur ? hi1 : hi0;
+	__shared__ float4 s_lo[RT_PLOC_T], s_hi[RT_PLOC_T];
+	__shared__ int s_nn[RT_PLOC_T];
+	__shared__ int s_ws[RT_PLOC_T / 64], s_wm[RT_PLOC_T / 64];
+	const int tid = (int)threadIdx.x;
+	const int p = base - 2 * RT_PLOC_R + tid;
+	const bool valid = p >= 0 && p < n;
+	if (valid) { s_lo[tid] = lo[p]; s_hi[tid] = hi[p]; }
+	__syncthreads();
+	int nn = -1;
+	if (valid && tid >= RT_PLOC_R && tid < RT_PLOC_T - RT_PLOC_R) {
+		const float4 alo = s_lo[tid], ahi = s_hi[tid];
+		float best = 0.f;
+#pragma unroll
+		for (int d = -RT_PLOC_R; d <= RT_PLOC_R; d++) {
+			if (d == 0) continue;
+			const int q = p + d;
+			if (q < 0 || q >= n) continue;
+			const float a = union_area(alo, ahi, s_lo[tid + d], s_hi[tid + d]);
+			if (nn < 0 || a < best) { best = a; nn = q; }            // ascending q, strict <: the lower index on ties
+		}
+	}
+	s_nn[tid] = nn;
+	__syncthreads();
+	const bool owned = valid && tid >= 2 * RT_PLOC_R && tid < RT_PLOC_T - 2 * RT_PLOC_R;
+	int kind = 0;
+	if (owned && nn >= 0 && s_nn[nn - (base - 2 * RT_PLOC_R)] == p) kind = p < nn ? 1 : 2;
+	const bool survive = owned && kind != 2, lead = owned && kind == 1;
+	const unsigned long long ms = __builtin_amdgcn_ballot_w64(survive), mm = __builtin_amdgcn_ballot_w64(lead);
+	const int lane = tid & 63, wv = tid >> 6;
+	const unsigned long long below = (1ull << lane) - 1ull;
+	int rs = __popcll(ms & below), rm = __popcll(mm & below);
+	if (lane == 0) { s_ws[wv] = __popcll(ms); s_wm[wv] = __popcll(mm); }
+	__syncthreads();
+	int ts = 0, tm = 0;
+#pragma unroll
+	for (int w = 0; w < RT_PLOC_T / 64; w++) {
+		if (w < wv) { rs += s_ws[w]; rm += s_wm[w]; }
+		ts += s_ws[w]; tm += s_wm[w];
+	}
+	if (owned) dec[p] = make_int2((rs << 2) | kind, (rm << 8) | (nn - p + 128));
+	if (tid == 0) totals[blockIdx.x] = make_int2(ts, tm);
+}
+
+__global__ void __launch_bounds__(RT_PLOC_T) k_ploc_merge(float4* __restrict__ lo0, float4* __restrict__ hi0, float4* __restrict__ lo1, float4* __restrict__ hi1,
+                                                         PlocState* __restrict__ state, int pass, const int2* __restrict__ dec,
+                                                         const int2* __restrict__ totals, float4* __restrict__ nodes, int nt) {
+	const PlocState st = state[pass];
+	const int n = st.n;
+	const int base = (int)blockIdx.x * RT_PLOC_C;
+	const int tid = (int)threadIdx.x;
+	if (n <= RT_PLOC_TAIL || st.fail) {                       // nothing to do in this pass (the tail kernel finishes): hand the state on
+		if (blockIdx.x == 0 && tid == 0) state[pass + 1] = st;
+		return;
+	}
+	if (base >= n) return;
+	const float4* __restrict__ lo = st.cur ? lo1 : lo0;
+	const float4* __restrict__ hi = st.cur ? hi1 : hi0;
+	float4* __restrict__ olo = st.cur ? lo0 : lo1;
+	float4* __restrict__ ohi = st.cur ? hi0 : hi1;
+	// survivors and merges of the workgroups before this one
+	__shared__ int s_s[RT_PLOC_T / 64], s_m[RT_PLOC_T / 64];
+	int ps = 0, pm = 0;
+	for (int k = tid; k < (int)blockIdx.x; k += RT_PLOC_T) { const int2 t = totals[k]; ps += t.x; pm += t.y; }
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) { ps += __shfl_down(ps, off); pm += __shfl_down(pm, off); }
+	if ((tid & 63) == 0) { s_s[tid >> 6] = ps; s_m[tid >> 6] = pm; }
+	__syncthreads();
+	ps = 0; pm = 0;
+#pragma unroll
+	for (int w = 0; w < RT_PLOC_T / 64; w++) { ps += s_s[w]; pm += s_m[w]; }
+	const int n_blocks = (n + RT_PLOC_C - 1) / RT_PLOC_C;
+	if ((int)blockIdx.x == n_blocks - 1 && tid == 0) {
+		const int2 mine = totals[blockIdx.x];
+		PlocState nx;
+		nx.n = ps + mine.x; nx.merges = st.merges + pm + mine.y; nx.cur = st.cur ^ 1;
+		nx.fail = (mine.y + pm) == 0;                          // no pair merged: the search cannot make progress (non-finite areas)
+		state[pass + 1] = nx;
+	}
+	const int p = base + tid;
+	if (tid >= RT_PLOC_C || p >= n) return;
+	const int2 d = dec[p];
+	const int kind = d.x & 3;
+	if (kind == 2) return;
+	const int pos = ps + (d.x >> 2);
+	float4 alo = lo[p], ahi = hi[p];
+	if (kind == 1) {
+		const int q = p + ((d.y & 255) - 128);
+		const float4 blo = lo[q], bhi = hi[q];
+		const int node = nt - 2 - (st.merges + pm + (d.y >> 8));
+		write_merged_node(nodes, node, alo, ahi, blo, bhi);
+		alo = make_float4(fminf(alo.x, blo.x), fminf(alo.y, blo.y), fminf(alo.z, blo.z), __int_as_float(node));
+		ahi = make_float4(fmaxf(ahi.x, bhi.x), fmaxf(ahi.y, bhi.y), fmaxf(ahi.z, bhi.z), 0.f);
+	}
+	olo[pos] = alo;
+	ohi[pos] = ahi;
+}
+
+// the last RT_PLOC_TAIL clusters (or a whole small scene): one workgroup, clusters in LDS, a barrier per step
+__global__ void __launch_bounds__(RT_PLOC_TAIL) k_ploc_tail(const float4* __restrict__ lo0, const float4* __restrict__ hi0, const float4* __restrict__ lo1,
+                                                           const float4* __restrict__ hi1, PlocState* __restrict__ state, int pass,
+                                                           float4* __restrict__ nodes, int nt) {
+	__shared__ float4 s_lo[RT_PLOC_TAIL], s_hi[RT_PLOC_TAIL];
+	__shared__ int s_nn[RT_PLOC_TAIL];
+	__shared__ int s_ws[RT_PLOC_TAIL / 64], s_wm[RT_PLOC_TAIL / 64];
+	PlocState st = state[pass];
+	const int tid = (int)threadIdx.x;
+	if (st.n > RT_PLOC_TAIL || st.fail) {                      // (the host only launches this once the count is small enough)
+		if (tid == 0) { st.fail = 1; state[pass + 1] = st; }
+		return;
+	}
+	int n = st.n, merges = st.merges;
+	{
+		const float4* __restrict__ lo = st.cur ? lo1 : lo0;
+		const float4* __restrict__ hi = st.cur ? hi1 : hi0;
+		if (tid < n) { s_lo[tid] = lo[tid]; s_hi[tid] = hi[tid]; }
+	}
+	__syncthreads();
+	const int lane = tid & 63, wv = tid >> 6;
+	const unsigned long long below = (1ull << lane) - 1ull;
+	int fail = 0;
+	while (n > 1) {
+		const bool valid = tid < n;
+		float4 alo = make_float4(0.f, 0.f, 0.f, 0.f), ahi = alo;
+		int nn = -1;
+		if (valid) {
+			alo = s_lo[tid]; ahi = s_hi[tid];
+			float best = 0.f;
+			for (int d = -RT_PLOC_R; d <= RT_PLOC_R; d++) {
+				const int q = tid + d;
+				if (d == 0 || q < 0 || q >= n) continue;
+				const float a = union_area(alo, ahi, s_lo[q], s_hi[q]);
+				if (nn < 0 || a < best) { best = a; nn = q; }
+			}
+		}
+		s_nn[tid] = nn;
+		__syncthreads();
+		int kind = 0;
+		if (valid && nn >= 0 && s_nn[nn] == tid) kind = tid < nn ? 1 : 2;
+		const bool survive = valid && kind != 2, lead = kind == 1;
+		const unsigned long long ms = __builtin_amdgcn_ballot_w64(survive), mm = __builtin_amdgcn_ballot_w64(lead);
+		int rs = __popcll(ms & below), rm = __popcll(mm & below);
+		if (lane == 0) { s_ws[wv] = __popcll(ms); s_wm[wv] = __popcll(mm); }
+		float4 blo = alo, bhi = ahi;
+		if (lead) { blo = s_lo[nn]; bhi = s_hi[nn]; }
+		__syncthreads();                                       // every read of the old clusters is done
+		int ts = 0, tm = 0;
+		for (int w = 0; w < RT_PLOC_TAIL / 64; w++) {
+			if (w < wv) { rs += s_ws[w]; rm += s_wm[w]; }
+			ts += s_ws[w]; tm += s_wm[w];
+		}
+		if (lead) {
+			const int node = nt - 2 - (merges + rm);
+			write_merged_node(nodes, node, alo, ahi, blo, bhi);
+			alo = make_float4(fminf(alo.x, blo.x), fminf(alo.y, blo.y), fminf(alo.z, blo.z), __int_as_float(node));
+			ahi = make_float4(fmaxf(ahi.x, bhi.x), fmaxf(ahi.y, bhi.y), fmaxf(ahi.z, bhi.z), 0.f);
+		}
+		if (survive) { s_lo[rs] = alo; s_hi[rs] = ahi; }
+		__syncthreads();                                       // (also keeps s_ws / s_wm for the next step's writers)
+		if (tm == 0) { fail = 1; break; }                      // wave-uniform and workgroup-uniform: everyone leaves together
+		n = ts;
+		merges += tm;
+	}
+	if (tid == 0) {
+		PlocState nx;
+		nx.n = n; nx.merges = merges; nx.cur = st.cur; nx.fail = fail;
+		state[pass + 1] = nx;
+	}
+}
+
 // Which triangles stay out of the tree: those whose vertex box has at least an eighth of the
 // surface area of the scene's box.  A ray meets such a box with that probability or more at every
 // level of the path from its leaf to the root, so leaving it in costs more box tests than the one
@@ -483,7 +719,6 @@ int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 	pick_hoisted(s->tris, d.bb_lo, d.bb_hi, hoisted);
 	const int nh = (int)hoisted.size();
 	const int nt = n - nh;                       // triangles in the tree
-	const bool sah = s->build == RT_BUILD_SAH;
 	const size_t hoist_float4s = (size_t)nh * (RT_AOS_F4 + 8 * 2);   // records, then 8 octants of boxes
 	int* hoist_idx = nullptr;
 	float4* hoist = nullptr;
@@ -492,6 +727,9 @@ int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 	unsigned int* flags = nullptr;
 	void* temp = nullptr;
 	float4 *nodes = nullptr, *aos = nullptr, *pkt = nullptr;
+	float4* cl[4] = { nullptr, nullptr, nullptr, nullptr };          // PLOC: cluster lo/hi, two buffers
+	int2 *dec = nullptr, *totals = nullptr;
+	PlocState* pstate = nullptr;
 	uint4* nodes4 = nullptr;
 	hipEvent_t e0 = nullptr, e1 = nullptr;
 	int rc = RT_OK;
@@ -503,11 +741,23 @@ int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 		if (flags) (void)hipFree(flags);
 		if (temp) (void)hipFree(temp);
 		if (hoist_idx) (void)hipFree(hoist_idx);
+		for (int k = 0; k < 4; k++) if (cl[k]) (void)hipFree(cl[k]);
+		if (dec) (void)hipFree(dec);
+		if (totals) (void)hipFree(totals);
+		if (pstate) (void)hipFree(pstate);
 		if (e0) (void)hipEventDestroy(e0);
 		if (e1) (void)hipEventDestroy(e1);
 	};
-#define LB_TRY(x) do { rc = (x); if (rc != RT_OK) { cleanup(); if (nodes) (void)hipFree(nodes); if (nodes4) (void)hipFree(nodes4); if (aos) (void)hipFree(aos); if (pkt) (void)hipFree(pkt); if (hoist) (void)hipFree(hoist); return rc; } } while (0)
-#define LB_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = hip_fail(e_, #x); cleanup(); if (nodes) (void)hipFree(nodes); if (nodes4) (void)hipFree(nodes4); if (aos) (void)hipFree(aos); if (pkt) (void)hipFree(pkt); if (hoist) (void)hipFree(hoist); return rc; } } while (0)
+	auto drop_results = [&]() {
+		if (nodes) (void)hipFree(nodes);
+		if (nodes4) (void)hipFree(nodes4);
+		if (aos) (void)hipFree(aos);
+		if (pkt) (void)hipFree(pkt);
+		if (hoist) (void)hipFree(hoist);
+	};
+#define LB_TRY(x) do { rc = (x); if (rc != RT_OK) { cleanup(); drop_results(); return rc; } } while (0)
+#define LB_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { rc = hip_fail(e_, #x); cleanup(); drop_results(); return rc; } } while (0)
+	const int ploc_blocks_max = (nt + RT_PLOC_C - 1) / RT_PLOC_C;
 	LB_TRY(dev_alloc(&keys, (size_t)n));
 	LB_TRY(dev_alloc(&keys_sorted, (size_t)n));
 	LB_TRY(dev_alloc(&parent_int, (size_t)n));
@@ -516,8 +766,13 @@ int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 	LB_TRY(dev_alloc(&nodes, (size_t)(nt - 1) * 4));
 	LB_TRY(dev_alloc(&nodes4, (size_t)(nt - 1) * 4));
 	LB_TRY(dev_alloc(&aos, (size_t)n * RT_AOS_F4));
-	const bool want_packet = true;
 	LB_TRY(dev_alloc(&pkt, (size_t)(nt - 1) * 4 * 8));
+	if (s->build == RT_BUILD_PLOC) {
+		for (int k = 0; k < 4; k++) LB_TRY(dev_alloc(&cl[k], (size_t)nt));
+		LB_TRY(dev_alloc(&dec, (size_t)nt));
+		LB_TRY(dev_alloc(&totals, (size_t)ploc_blocks_max));
+		LB_TRY(dev_alloc(&pstate, (size_t)RT_PLOC_MAX_PASSES + 2));
+	}
 	if (nh > 0) {
 		LB_TRY(dev_alloc(&hoist_idx, (size_t)nh));
 		LB_TRY(dev_alloc(&hoist, hoist_float4s));
@@ -553,100 +808,135 @@ int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 	const unsigned int blocks_n = (unsigned int)((n + 255) / 256);
 	const unsigned int blocks_t = (unsigned int)((nt + 255) / 256);
 
-	float host_ms = 0.f;
-	std::vector<u64> h_keys;
-	std::vector<int> h_child, h_pint, h_pleaf, h_nodes;
-	if (sah) {
-		const auto t0 = std::chrono::steady_clock::now();
-		try { sah_topology(s->tris, hoisted, nt, h_keys, h_child, h_pint, h_pleaf); }
-		catch (...) { set_error("LBVH (SAH build): out of host memory or threads"); rc = RT_ERR_NOMEM; }
-		LB_TRY(rc);
-		// whole nodes with only the child references set (k_refit fills the boxes): one contiguous upload
-		try {
-			h_nodes.assign((size_t)(nt - 1) * 16, 0);
-			for (size_t i = 0; i < (size_t)(nt - 1); i++) { h_nodes[i * 16 + 12] = h_child[i * 2]; h_nodes[i * 16 + 13] = h_child[i * 2 + 1]; }
-		} catch (...) { set_error("LBVH (SAH build): out of host memory"); rc = RT_ERR_NOMEM; }
-		LB_TRY(rc);
-		host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-	}
-	LB_HIP(hipEventRecord(e0, stream));
-	LB_HIP(hipMemsetAsync(flags, 0, (size_t)n * sizeof(unsigned int), stream));
-	LB_HIP(hipMemsetAsync(nodes, 0, (size_t)(nt - 1) * 4 * sizeof(float4), stream));
-	hipLaunchKernelGGL(k_morton, dim3(blocks_n), dim3(256), 0, stream, planes, d.stride, n, scene, index_bits, keys);
-	LB_HIP(hipGetLastError());
-	if (nh > 0) {
-		hipLaunchKernelGGL(k_hoist, dim3(1), dim3(64), 0, stream, planes, d.stride, (const int*)hoist_idx, nh, pad, keys, hoist);
+	float ms = 0.f, host_ms = 0.f;
+	int depth2 = 0, depth4 = 0;
+	int built = s->build;                            // what the tree was really built by (PLOC may fall back)
+	for (int attempt = 0; attempt < 2; attempt++) {
+		const bool sah = built == RT_BUILD_SAH, ploc = built == RT_BUILD_PLOC;
+		std::vector<u64> h_keys;
+		std::vector<int> h_child, h_pint, h_pleaf, h_nodes;
+		host_ms = 0.f;
+		if (sah) {
+			const auto t0 = std::chrono::steady_clock::now();
+			try { sah_topology(s->tris, hoisted, nt, h_keys, h_child, h_pint, h_pleaf); }
+			catch (...) { set_error("LBVH (SAH build): out of host memory or threads"); rc = RT_ERR_NOMEM; }
+			LB_TRY(rc);
+			// whole nodes with only the child references set (k_refit fills the boxes): one contiguous upload
+			try {
+				h_nodes.assign((size_t)(nt - 1) * 16, 0);
+				for (size_t i = 0; i < (size_t)(nt - 1); i++) { h_nodes[i * 16 + 12] = h_child[i * 2]; h_nodes[i * 16 + 13] = h_child[i * 2 + 1]; }
+			} catch (...) { set_error("LBVH (SAH build): out of host memory"); rc = RT_ERR_NOMEM; }
+			LB_TRY(rc);
+			host_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+		}
+		LB_HIP(hipEventRecord(e0, stream));
+		if (!ploc) {
+			LB_HIP(hipMemsetAsync(flags, 0, (size_t)n * sizeof(unsigned int), stream));
+			LB_HIP(hipMemsetAsync(nodes, 0, (size_t)(nt - 1) * 4 * sizeof(float4), stream));
+		}
+		hipLaunchKernelGGL(k_morton, dim3(blocks_n), dim3(256), 0, stream, planes, d.stride, n, scene, index_bits, keys);
 		LB_HIP(hipGetLastError());
-	}
-	unsigned int leaf_mask = index_mask;
-	if (sah) {
-		// the host's topology in place of sort + k_karras: leaf order, child references (the fourth float4 of a node), parent links
-		LB_HIP(hipMemcpyAsync(keys_sorted, h_keys.data(), (size_t)nt * sizeof(u64), hipMemcpyHostToDevice, stream));
-		LB_HIP(hipMemcpyAsync(nodes, h_nodes.data(), (size_t)(nt - 1) * 64, hipMemcpyHostToDevice, stream));
-		LB_HIP(hipMemcpyAsync(parent_int, h_pint.data(), (size_t)nt * sizeof(int), hipMemcpyHostToDevice, stream));
-		LB_HIP(hipMemcpyAsync(parent_leaf, h_pleaf.data(), (size_t)nt * sizeof(int), hipMemcpyHostToDevice, stream));
-		leaf_mask = 0xffffffffu;
-	} else {
-		LB_HIP(rocprim::radix_sort_keys(temp, temp_bytes, keys, keys_sorted, (size_t)n, 0, key_bits, stream));
-		// (the hoisted keys sorted to the tail: the tree is built over the first nt)
-		hipLaunchKernelGGL(k_karras, dim3(blocks_t), dim3(256), 0, stream, keys_sorted, nt, index_mask, nodes, parent_int, parent_leaf);
+		if (nh > 0) {
+			hipLaunchKernelGGL(k_hoist, dim3(1), dim3(64), 0, stream, planes, d.stride, (const int*)hoist_idx, nh, pad, keys, hoist);
+			LB_HIP(hipGetLastError());
+		}
+		unsigned int leaf_mask = index_mask;
+		bool ploc_failed = false;
+		if (sah) {
+			// the host's topology in place of sort + k_karras: leaf order, child references (the fourth float4 of a node), parent links
+			LB_HIP(hipMemcpyAsync(keys_sorted, h_keys.data(), (size_t)nt * sizeof(u64), hipMemcpyHostToDevice, stream));
+			LB_HIP(hipMemcpyAsync(nodes, h_nodes.data(), (size_t)(nt - 1) * 64, hipMemcpyHostToDevice, stream));
+			LB_HIP(hipMemcpyAsync(parent_int, h_pint.data(), (size_t)nt * sizeof(int), hipMemcpyHostToDevice, stream));
+			LB_HIP(hipMemcpyAsync(parent_leaf, h_pleaf.data(), (size_t)nt * sizeof(int), hipMemcpyHostToDevice, stream));
+			leaf_mask = 0xffffffffu;
+		} else {
+			LB_HIP(rocprim::radix_sort_keys(temp, temp_bytes, keys, keys_sorted, (size_t)n, 0, key_bits, stream));
+			// (the hoisted keys sorted to the tail: the tree is built over the first nt)
+		}
+		if (ploc) {
+			hipLaunchKernelGGL(k_ploc_init, dim3(blocks_t), dim3(256), 0, stream, planes, d.stride, nt, (const u64*)keys_sorted, index_mask, pad,
+			                   cl[0], cl[1], pstate);
+			LB_HIP(hipGetLastError());
+			int pass = 0, n_upper = nt;
+			PlocState hs = { nt, 0, 0, 0 };
+			while (n_upper > RT_PLOC_TAIL && !ploc_failed) {
+				if (pass >= RT_PLOC_MAX_PASSES) { ploc_failed = true; break; }
+				const int batch = RT_PLOC_MAX_PASSES - pass < 8 ? RT_PLOC_MAX_PASSES - pass : 8;
+				const dim3 grid((unsigned int)((n_upper + RT_PLOC_C - 1) / RT_PLOC_C));
+				for (int b = 0; b < batch; b++, pass++) {
+					hipLaunchKernelGGL(k_ploc_search, grid, dim3(RT_PLOC_T), 0, stream, (const float4*)cl[0], (const float4*)cl[1], (const float4*)cl[2],
+					                   (const float4*)cl[3], (const PlocState*)pstate, pass, dec, totals);
+					hipLaunchKernelGGL(k_ploc_merge, grid, dim3(RT_PLOC_T), 0, stream, cl[0], cl[1], cl[2], cl[3], pstate, pass, (const int2*)dec,
+					                   (const int2*)totals, nodes, nt);
+				}
+				LB_HIP(hipGetLastError());
+				LB_HIP(hipMemcpyAsync(&hs, pstate + pass, sizeof hs, hipMemcpyDeviceToHost, stream));
+				LB_HIP(hipStreamSynchronize(stream));
+				if (hs.fail || hs.n < 1 || hs.n > n_upper) ploc_failed = true;
+				n_upper = hs.n;
+			}
+			if (!ploc_failed) {
+				hipLaunchKernelGGL(k_ploc_tail, dim3(1), dim3(RT_PLOC_TAIL), 0, stream, (const float4*)cl[0], (const float4*)cl[1], (const float4*)cl[2],
+				                   (const float4*)cl[3], pstate, pass, nodes, nt);
+				LB_HIP(hipGetLastError());
+				pass++;
+				LB_HIP(hipMemcpyAsync(&hs, pstate + pass, sizeof hs, hipMemcpyDeviceToHost, stream));
+				LB_HIP(hipStreamSynchronize(stream));
+				if (hs.fail || hs.n != 1 || hs.merges != nt - 1) ploc_failed = true;
+			}
+		} else {
+			if (!sah) {
+				hipLaunchKernelGGL(k_karras, dim3(blocks_t), dim3(256), 0, stream, keys_sorted, nt, index_mask, nodes, parent_int, parent_leaf);
+				LB_HIP(hipGetLastError());
+			}
+			hipLaunchKernelGGL(k_refit, dim3(blocks_t), dim3(256), 0, stream, planes, d.stride, nt, keys_sorted, leaf_mask, (float*)nodes,
+			                   parent_int, parent_leaf, flags, pad);
+			LB_HIP(hipGetLastError());
+		}
+		if (ploc_failed) { built = RT_BUILD_FAST; continue; }      // clustering made no progress (areas that overflow): the Morton/Karras tree instead
+		hipLaunchKernelGGL(k_collapse4, dim3(blocks_t), dim3(256), 0, stream, (const float4*)nodes, nt - 1, nodes4);
 		LB_HIP(hipGetLastError());
-	}
-	hipLaunchKernelGGL(k_refit, dim3(blocks_t), dim3(256), 0, stream, planes, d.stride, nt, keys_sorted, leaf_mask, (float*)nodes,
-	                   parent_int, parent_leaf, flags, pad);
-	LB_HIP(hipGetLastError());
-	hipLaunchKernelGGL(k_collapse4, dim3(blocks_t), dim3(256), 0, stream, (const float4*)nodes, nt - 1, nodes4);
-	LB_HIP(hipGetLastError());
-	hipLaunchKernelGGL(k_aos, dim3(blocks_n), dim3(256), 0, stream, planes, d.stride, n, aos);
-	LB_HIP(hipGetLastError());
-	if (want_packet) {
+		hipLaunchKernelGGL(k_aos, dim3(blocks_n), dim3(256), 0, stream, planes, d.stride, n, aos);
+		LB_HIP(hipGetLastError());
 		hipLaunchKernelGGL(k_packet, dim3(blocks_t), dim3(256), 0, stream, (const float4*)nodes, nt - 1, pkt);
 		LB_HIP(hipGetLastError());
+		LB_HIP(hipEventRecord(e1, stream));
+		LB_HIP(hipEventSynchronize(e1));
+		LB_HIP(hipEventElapsedTime(&ms, e0, e1));
+		if (!ploc) {
+			// the root must have been reached by exactly two arrivals
+			unsigned int root_flag = 0;
+			LB_HIP(hipMemcpy(&root_flag, flags, sizeof root_flag, hipMemcpyDeviceToHost));
+			if (root_flag != 2) {
+				set_error("LBVH refit did not reach the root (flag %u)", root_flag);
+				cleanup();
+				drop_results();
+				return RT_ERR_DEVICE;
+			}
+		}
+		// Depths of the binary tree and of its 4-wide collapse, from host copies of the child references
+		// (16 B of every 64-byte node): what the traversal stacks have to hold (rt_lbvh_trav.inl header).
+		try {
+			// (whole arrays in one copy each: a strided hipMemcpy2D of 16 bytes per node takes a second per 100k nodes)
+			std::vector<int> all((size_t)(nt - 1) * 16), refs((size_t)(nt - 1) * 4);
+			LB_HIP(hipMemcpy(all.data(), nodes, (size_t)(nt - 1) * 64, hipMemcpyDeviceToHost));
+			for (size_t i = 0; i < (size_t)(nt - 1); i++) { refs[i * 2] = all[i * 16 + 12]; refs[i * 2 + 1] = all[i * 16 + 13]; }   // q3 = (left, right, 0, 0)
+			depth2 = tree_depth(refs, 2, nt - 1);
+			LB_HIP(hipMemcpy(all.data(), nodes4, (size_t)(nt - 1) * 64, hipMemcpyDeviceToHost));
+			for (size_t i = 0; i < (size_t)(nt - 1); i++)
+				for (int c = 0; c < 4; c++) { const int r = all[i * 16 + 4 + c]; refs[i * 4 + c] = r == RT_BVH4_EMPTY ? -1 : r; }       // w1 = the 4 child references
+			depth4 = tree_depth(refs, 4, nt - 1);
+		} catch (...) { set_error("LBVH: out of host memory measuring the tree"); rc = RT_ERR_NOMEM; }
+		LB_TRY(rc);
+		if (ploc && depth2 > 63 && depth4 >= 1) { built = RT_BUILD_FAST; continue; }    // an agglomerated chain deeper than the packet stack: Karras' tree is at most 63 deep
+		break;
 	}
-	LB_HIP(hipEventRecord(e1, stream));
-	LB_HIP(hipEventSynchronize(e1));
-	float ms = 0.f;
-	LB_HIP(hipEventElapsedTime(&ms, e0, e1));
-	// the root must have been reached by exactly two arrivals
-	unsigned int root_flag = 0;
-	LB_HIP(hipMemcpy(&root_flag, flags, sizeof root_flag, hipMemcpyDeviceToHost));
-	if (root_flag != 2) {
-		set_error("LBVH refit did not reach the root (flag %u)", root_flag);
-		cleanup();
-		(void)hipFree(nodes);
-		(void)hipFree(nodes4);
-		(void)hipFree(aos);
-		if (pkt) (void)hipFree(pkt);
-		if (hoist) (void)hipFree(hoist);
-		return RT_ERR_DEVICE;
-	}
-	// Depths of the binary tree and of its 4-wide collapse, from host copies of the child references
-	// (16 B of every 64-byte node): what the traversal stacks have to hold (rt_lbvh_trav.inl header).
-	int depth2 = 0, depth4 = 0;
-	try {
-		// (whole arrays in one copy each: a strided hipMemcpy2D of 16 bytes per node takes a second per 100k nodes)
-		std::vector<int> all((size_t)(nt - 1) * 16), refs((size_t)(nt - 1) * 4);
-		LB_HIP(hipMemcpy(all.data(), nodes, (size_t)(nt - 1) * 64, hipMemcpyDeviceToHost));
-		for (size_t i = 0; i < (size_t)(nt - 1); i++) { refs[i * 2] = all[i * 16 + 12]; refs[i * 2 + 1] = all[i * 16 + 13]; }   // q3 = (left, right, 0, 0)
-		depth2 = tree_depth(refs, 2, nt - 1);
-		LB_HIP(hipMemcpy(all.data(), nodes4, (size_t)(nt - 1) * 64, hipMemcpyDeviceToHost));
-		for (size_t i = 0; i < (size_t)(nt - 1); i++)
-			for (int c = 0; c < 4; c++) { const int r = all[i * 16 + 4 + c]; refs[i * 4 + c] = r == RT_BVH4_EMPTY ? -1 : r; }       // w1 = the 4 child references
-		depth4 = tree_depth(refs, 4, nt - 1);
-	} catch (...) { set_error("LBVH: out of host memory measuring the tree"); rc = RT_ERR_NOMEM; }
-	if (rc == RT_OK && (depth2 < 1 || depth4 < 1 || depth2 > 63)) {
+	if (depth2 < 1 || depth4 < 1 || depth2 > 63) {
 		// (63-bit unique keys bound the Karras tree at 63 levels, RT_SAH_MEDIAN_DEPTH the SAH tree: the packet stack has 64 entries)
 		set_error("LBVH: malformed tree (binary depth %d, 4-wide depth %d)", depth2, depth4);
-		rc = RT_ERR_DEVICE;
-	}
-	if (rc != RT_OK) {
 		cleanup();
-		(void)hipFree(nodes);
-		(void)hipFree(nodes4);
-		(void)hipFree(aos);
-		if (pkt) (void)hipFree(pkt);
-		if (hoist) (void)hipFree(hoist);
-		return rc;
+		drop_results();
+		return RT_ERR_DEVICE;
 	}
 #undef LB_TRY
 #undef LB_HIP
@@ -665,6 +955,7 @@ int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 	d.bvh4_depth = depth4;
 	d.per_lane_ok = 3 * depth4 <= RT_STACK_LIMIT;
 	d.build_ms = ms + host_ms;
+	d.built_by = built;
 	return RT_OK;
 }
 

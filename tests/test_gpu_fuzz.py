@@ -45,7 +45,7 @@ def render_all_paths(desc):
         for kind, kname in ((api.KERNEL_LOCKSTEP, "lockstep"), (api.KERNEL_STATE_MACHINE, "state machine")):
             sc.set_kernel(kind)
             frames.append(("brute/" + kname, sc.render(desc.cam_pos, tr, desc.width, desc.height, desc.depth)))
-        for build, bname in ((api.BUILD_SAH, "sah"), (api.BUILD_FAST, "morton")):
+        for build, bname in ((api.BUILD_PLOC, "ploc"), (api.BUILD_SAH, "sah"), (api.BUILD_FAST, "morton")):
             sc.set_build(build)
             sc.commit(0, api.ACCEL_LBVH)
             hoisted = int(sc.hoisted(0).size)

@@ -46,7 +46,7 @@ def test_glsl_through_the_tree_tiles_batches_rgba8_and_async(oracle):
     tr = api.camera_trans(desc.cam_rot)
     W, H = desc.width, desc.height
     with api.Scene.from_desc(desc) as sc:
-        for build in (api.BUILD_SAH, api.BUILD_FAST):
+        for build in (api.BUILD_PLOC, api.BUILD_SAH, api.BUILD_FAST):
             sc.set_build(build)
             sc.commit(0, api.ACCEL_LBVH)
             for mode in (api.TRAVERSAL_PER_LANE, api.TRAVERSAL_PACKET):
