@@ -305,6 +305,20 @@ int         rt_scene_set_build(rt_scene* s, int quality);
 /* What really built the tree of the last LBVH commit on `device`: RT_BUILD_PLOC, _SAH or _FAST (a PLOC commit that
  * fell back reports FAST); RT_ERR_STATE for a brute-force commit.  No counterpart in the reference. */
 int         rt_scene_build_kind(const rt_scene* s, int device);
+/* Tuning knob of one scene: direction grids for the shadow rays of LBVH commits (1, the default: on; 0: off; takes effect
+ * at the next rt_scene_commit, committed trees of the scene become stale).  Pixels do not depend on it.  processLighting's
+ * rays (Src:470-476) all end at a light, so as seen from the light each is ONE direction: per light (the first
+ * RT_SHADOW_GRID_LIGHTS of the scene) the commit bins the triangles of the tree into a cube map of direction cells around
+ * the light, nearest first, on the GPU; a shadow ray then tests the few triangles of its own cell that lie nearer the light
+ * than its origin — with the reference's arithmetic — instead of walking the tree.  About half the rays of a frame are
+ * shadow rays.  Lights beyond the limit, and lights crowded by geometry (more than 32 triangles within 1/250 of the scene
+ * size of the light, or wider than half their distance from it), keep the tree walk. */
+#define RT_SHADOW_GRID_LIGHTS 4
+int         rt_scene_set_shadow_grid(rt_scene* s, int on);
+/* The grid of light `light` from the last commit on `device` (tests, tools): cells per cube-face edge (0: this light has no
+ * grid), list entries, triangles on the light's "always" list, and the GPU time of the commit's grid builds (all lights).
+ * Any out pointer may be NULL.  No counterpart in the reference. */
+int         rt_scene_shadow_grid(const rt_scene* s, int device, int light, int* cells_per_edge, long long* entries, int* always, float* build_ms);
 /* Tuning knob of one scene: how its LBVH is traversed.  RT_TRAVERSAL_AUTO lets each launch choose
  * by the coherence of an 8x8 tile of rays against the scene's triangles; both give
  * the reference's bits.  A preference: a tree too deep for the per-lane stack (rt_scene_bvh_depth)

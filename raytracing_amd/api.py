@@ -43,7 +43,7 @@ SYMBOLS = (
     "rt_camera_translate", "rt_camera_frame_time", "rt_camera_step", "rt_camera_path", "rt_render", "rt_render_device",
     "rt_render_frames_device", "rt_render_tiles_device", "rt_shard_rows", "rt_render_stats", "rt_render_multi", "rt_cast_rays",
     "rt_render_async", "rt_render_wait", "rt_frame_alloc", "rt_frame_free", "rt_cast_rays_noalloc",
-    "rt_device_count", "rt_device_props", "rt_scene_set_tiles_per_wave", "rt_scene_set_traversal", "rt_scene_set_kernel", "rt_scene_set_build", "rt_scene_build_kind", "rt_scene_traversal", "rt_last_error", "rt_version",
+    "rt_device_count", "rt_device_props", "rt_scene_set_tiles_per_wave", "rt_scene_set_traversal", "rt_scene_set_kernel", "rt_scene_set_build", "rt_scene_build_kind", "rt_scene_set_shadow_grid", "rt_scene_shadow_grid", "rt_scene_traversal", "rt_last_error", "rt_version",
 )
 
 
@@ -155,6 +155,8 @@ def lib():
     L.rt_scene_set_kernel.argtypes = [vp, ci]
     L.rt_scene_set_build.argtypes = [vp, ci]
     L.rt_scene_build_kind.argtypes = [vp, ci]
+    L.rt_scene_set_shadow_grid.argtypes = [vp, ci]
+    L.rt_scene_shadow_grid.argtypes = [vp, ci, ci, C.POINTER(ci), C.POINTER(C.c_longlong), C.POINTER(ci), C.POINTER(cf)]
     L.rt_scene_bvh_depth.argtypes = [vp, ci, C.POINTER(ci), C.POINTER(ci)]
     L.rt_render_async.argtypes = [vp, _fp, _fp, ci, ci, ci, ci, vp]
     L.rt_render_wait.argtypes = [vp, ci]
@@ -431,6 +433,17 @@ class Scene:
         _check(lib().rt_scene_set_build(self._h, int(quality)))
         return self
 
+    def set_shadow_grid(self, on: bool) -> "Scene":
+        """Per-light direction grids for the shadow rays of LBVH commits (rt_scene_set_shadow_grid; on by default)."""
+        _check(lib().rt_scene_set_shadow_grid(self._h, 1 if on else 0))
+        return self
+
+    def shadow_grid(self, device: int = 0, light: int = 0) -> dict:
+        """{cells_per_edge, entries, always, build_ms} of one light's grid (rt_scene_shadow_grid); cells_per_edge 0: none."""
+        r, e, a, ms = C.c_int(0), C.c_longlong(0), C.c_int(0), C.c_float(0)
+        _check(lib().rt_scene_shadow_grid(self._h, int(device), int(light), C.byref(r), C.byref(e), C.byref(a), C.byref(ms)))
+        return {"cells_per_edge": int(r.value), "entries": int(e.value), "always": int(a.value), "build_ms": float(ms.value)}
+
     def build_kind(self, device: int = 0) -> int:
         """BUILD_* the tree of the last LBVH commit was really built by (a PLOC commit that fell back reports BUILD_FAST)."""
         return _check(lib().rt_scene_build_kind(self._h, int(device)))
@@ -556,10 +569,11 @@ class Scene:
 
 
 def render_desc(desc, device: int = 0, accel: int = ACCEL_AUTO, mode: int = STRICT,
-                traversal: int = TRAVERSAL_AUTO) -> np.ndarray:
+                traversal: int = TRAVERSAL_AUTO, shadow_grid: bool = True) -> np.ndarray:
     """Scene description -> frame, the way the reference's main() would: build, commit, render."""
     with Scene.from_desc(desc) as sc:
         sc.set_traversal(traversal)
+        sc.set_shadow_grid(shadow_grid)
         sc.commit(device, accel)
         return sc.render(desc.cam_pos, camera_trans(desc.cam_rot), desc.width, desc.height, desc.depth, mode)
 

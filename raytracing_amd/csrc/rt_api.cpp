@@ -70,6 +70,9 @@ void free_device_state(DeviceState& d) {
 	int prev = -1;
 	(void)hipGetDevice(&prev);
 	if (hipSetDevice(d.device) == hipSuccess) {
+		// frames in flight (rt_render_async) finish before anything they use goes away
+		if (d.render_stream) (void)hipStreamSynchronize(d.render_stream);
+		if (d.copy_stream) (void)hipStreamSynchronize(d.copy_stream);
 		if (d.planes) (void)hipFree(d.planes);
 		if (d.lights) (void)hipFree(d.lights);
 		if (d.counters) (void)hipFree(d.counters);
@@ -80,9 +83,10 @@ void free_device_state(DeviceState& d) {
 			if (d.rendered[k]) (void)hipEventDestroy(d.rendered[k]);
 			if (d.copied[k]) (void)hipEventDestroy(d.copied[k]);
 		}
-		if (d.render_stream) { (void)hipStreamSynchronize(d.render_stream); (void)hipStreamDestroy(d.render_stream); }
-		if (d.copy_stream) { (void)hipStreamSynchronize(d.copy_stream); (void)hipStreamDestroy(d.copy_stream); }
+		if (d.render_stream) (void)hipStreamDestroy(d.render_stream);
+		if (d.copy_stream) (void)hipStreamDestroy(d.copy_stream);
 		lbvh_free(d);
+		lgrid_free(d);
 	}
 	if (prev >= 0) (void)hipSetDevice(prev);
 	d = DeviceState();
@@ -269,6 +273,29 @@ int rt_scene_set_build(rt_scene* s, int quality) {
 	return RT_OK;
 }
 
+int rt_scene_set_shadow_grid(rt_scene* s, int on) {
+	if (!s) { set_error("rt_scene_set_shadow_grid: NULL scene"); return RT_ERR_INVALID; }
+	if (on != 0 && on != 1) { set_error("rt_scene_set_shadow_grid: %d is neither 0 nor 1", on); return RT_ERR_INVALID; }
+	if (s->shadow_grid != on) {
+		s->shadow_grid = on;
+		for (auto& kv : s->dev) if (kv.second.accel == RT_ACCEL_LBVH) kv.second.valid = false;      // grids are made (or dropped) at the next commit
+	}
+	return RT_OK;
+}
+
+int rt_scene_shadow_grid(const rt_scene* s, int device, int light, int* cells_per_edge, long long* entries, int* always, float* build_ms) {
+	if (!s || light < 0) { set_error("rt_scene_shadow_grid: bad argument"); return RT_ERR_INVALID; }
+	auto it = s->dev.find(device);
+	if (it == s->dev.end() || !it->second.valid) { set_error("rt_scene_shadow_grid: not committed on device %d", device); return RT_ERR_STATE; }
+	const DeviceState& d = it->second;
+	const bool have = d.accel == RT_ACCEL_LBVH && light < d.n_lgrid && (size_t)light * 3 + 2 < d.lgrid_info.size();
+	if (cells_per_edge) *cells_per_edge = have ? (int)d.lgrid_info[(size_t)light * 3] : 0;
+	if (entries) *entries = have ? d.lgrid_info[(size_t)light * 3 + 1] : 0;
+	if (always) *always = have ? (int)d.lgrid_info[(size_t)light * 3 + 2] : 0;
+	if (build_ms) *build_ms = d.accel == RT_ACCEL_LBVH ? d.lgrid_ms : 0.f;
+	return RT_OK;
+}
+
 int rt_scene_build_kind(const rt_scene* s, int device) {
 	if (!s) { set_error("rt_scene_build_kind: NULL scene"); return RT_ERR_INVALID; }
 	auto it = s->dev.find(device);
@@ -352,6 +379,8 @@ int rt_scene_commit(rt_scene* s, int device, int accel_flags) {
 		const float g = pad * 3e4f;
 		if (d.far_guard > g) d.far_guard = g;
 		int rc = lbvh_build(s, d, nullptr);
+		if (rc != RT_OK) return rc;
+		rc = lgrid_build(s, d, nullptr);
 		if (rc != RT_OK) return rc;
 	}
 	{   // set-up for rt_cast_rays_noalloc: this device's address of the library's staging array

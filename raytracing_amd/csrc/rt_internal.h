@@ -41,8 +41,28 @@ enum { PL_N = 0, PL_P1, PL_P2, PL_P3, PL_E0, PL_E1, PL_E2, PL_GLO, PL_GHI, PL_CL
 // (ACCEL 1).  The scene itself is read through the scalar cache in both.
 #define RT_LDS_MAX_TRIS 1024
 
+
 // LBVH: at most this many scene-spanning triangles are hoisted out of the tree (DevScene::hoist)
 #define RT_HOIST_MAX 32
+
+// Per-light direction grid for shadow rays (rt_lgrid.hip): one record per light in device memory (DevScene::lgrid).
+#define RT_LGRID_MAX_LIGHTS 4
+#define RT_LGRID_OVER_MAX 32
+struct LightGrid {
+	const int* cell_start;    // 6 * R * R + 1 offsets into `entries`; cell ((face * R + v) * R + u)
+	const int2* entries;      // (bits of the distance from the light to the triangle's padded box, triangle index); per cell ascending by distance
+	int R;                    // cells per face edge; 0: no grid for this light (its shadow rays walk the tree)
+	float half_R;
+	float slack;              // added to a ray's length before the distance cut-off of its list
+	int n_over;               // triangles tested for every ray of this light (near the light, or wide as seen from it)
+	int over[RT_LGRID_OVER_MAX];
+	// The triangles kept out of the tree (DevScene::hoist), by direction: per coarse cell (RT_LGRID_HC x RT_LGRID_HC per cube face) a
+	// bit mask of the hoisted triangles whose padded box may be seen in it, their distance from the light and their indices
+	const unsigned int* hmask;   // 6 * RT_LGRID_HC * RT_LGRID_HC words
+	float hmind[RT_HOIST_MAX];
+	int hidx[RT_HOIST_MAX];
+};
+#define RT_LGRID_HC 16
 
 struct DevScene {
 	const float4* planes;   // PL_COUNT * stride float4
@@ -82,6 +102,9 @@ struct DevScene {
 	int traversal;          // rt_scene_set_traversal: RT_TRAVERSAL_AUTO | _PER_LANE | _PACKET (host side only)
 	int kernel_kind;        // rt_scene_set_kernel (host side only)
 	int per_lane_ok;        // 0: the 4-wide tree is too deep for the per-lane stack (RT_STACK_MAX); packets only
+	const LightGrid* lgrid; // records for the first n_lgrid lights (LBVH commits; null / 0: none)
+	int n_lgrid;
+	int debug;              // RT_EXPERIMENT builds: switches for timing experiments (0 otherwise)
 };
 
 // Per-launch frame description.  Rows are addressed as LOCAL rows of this shard:
@@ -148,6 +171,12 @@ struct DeviceState {
 	int bvh_root = 0;
 	int stride = 0;
 	float build_ms = 0.f;
+	// per-light shadow grids (rt_lgrid.hip)
+	void* lgrid = nullptr;                 // n_lgrid LightGrid records
+	int n_lgrid = 0;
+	std::vector<void*> lgrid_buffers;      // cell offsets and entry lists the records point to
+	std::vector<long long> lgrid_info;     // per light: R, entries, "always" triangles
+	float lgrid_ms = 0.f;
 	int built_by = -1;           // RT_BUILD_* the tree of this commit was really built by (PLOC falls back to FAST when it cannot finish)
 	float bb_lo[3] = { 0, 0, 0 }, bb_hi[3] = { 0, 0, 0 };
 	float far_guard = 0.f;
@@ -182,6 +211,7 @@ struct rt_scene {
 	long long next_ticket = 0;            // rt_render_async
 	int kernel_kind = RT_KERNEL_AUTO;     // rt_scene_set_kernel
 	int build = RT_BUILD_PLOC;            // rt_scene_set_build (takes effect at the next LBVH commit)
+	int shadow_grid = 1;                  // rt_scene_set_shadow_grid (takes effect at the next LBVH commit)
 	int uv_w = -1, uv_h = -1;             // frame size the division-free u, v were last checked for (rt_api.cpp fill_frame)
 	bool uv_fast = false;
 };
@@ -214,5 +244,9 @@ int launch_cast_rays(const DevScene& sc, int accel, int n, const float* d_rays7,
 // rt_lbvh.hip
 int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream);
 void lbvh_free(DeviceState& d);
+
+// rt_lgrid.hip
+int lgrid_build(rt_scene* s, DeviceState& d, hipStream_t stream);
+void lgrid_free(DeviceState& d);
 
 } // namespace rt

@@ -708,24 +708,47 @@ __device__ __forceinline__ void flush_counters(unsigned long long* g, const unsi
 // larger scenes); 2: LBVH, per-lane walk of the 4-wide tree (rt_lbvh_trav.inl); 3: LBVH, wave-uniform packet walk.
 // `shadow`: the lane's ray is a shadow ray towards a light at distance `dist`.
 // `all_primary` (wave-uniform): every live lane holds a primary ray from the camera.
+// `li`: for a shadow ray, the index of the light it is aimed at (per lane; the state machine's lanes may be at different lights).
 template <int ACCEL, bool COUNT>
 __device__ __forceinline__ Hit trace(const DevScene& sc, const float4* lds_tri, int lds_stride, const float* lds_num0,
-                                     vec3 o, vec3 d, int skip, bool live, bool shadow, float dist, bool all_primary,
+                                     vec3 o, vec3 d, int skip, bool live, bool shadow, float dist, int li, bool all_primary,
                                      LaneCounters& lc, WaveProf& wp);
 
 } // namespace rt
 
 #include "rt_lbvh_trav.inl"
+#include "rt_lgrid_trav.inl"
 
 namespace rt {
 
+// Shadow rays of lights that have a direction grid (rt_lgrid.hip), for a wave whose lanes may be aimed at different lights:
+// one pass per light present.  Returns the lanes that were served; their result is in `hg`.
+template <bool COUNT>
+__device__ __forceinline__ bool shadow_by_grids(const DevScene& sc, vec3 o, vec3 d, int skip, bool live, bool shadow, float dist, int li,
+                                                Hit& hg, LaneCounters& lc, WaveProf& wp) {
+	bool served = false;
+	const bool wants = live && shadow && li >= 0 && li < sc.n_lgrid;
+	unsigned long long todo = __builtin_amdgcn_ballot_w64(wants);
+	while (todo) {
+		const int l = __builtin_amdgcn_readlane(li, __builtin_ctzll(todo));
+		const bool mine = wants && li == l;
+		todo &= ~__builtin_amdgcn_ballot_w64(mine);
+		const __attribute__((address_space(4))) LightGrid* G = (const __attribute__((address_space(4))) LightGrid*)(unsigned long long)(sc.lgrid + l);
+		if (G->R <= 0) continue;                                   // this light has no grid: the tree, with everybody else
+		const float4 L4 = c4ptr_of(sc.lights)[(unsigned int)l];
+		const Hit x = grid_shadow<COUNT>(sc, l, make3(L4.x, L4.y, L4.z), o, d, skip, mine, dist, lc, wp);
+		if (mine) { hg = x; served = true; }
+	}
+	return served;
+}
+
+// castRay over the tree for lanes of any kind (state-machine kernel, ray batches): per lane (ACCEL 2) or by packets (3)
 template <int ACCEL, bool COUNT>
-__device__ __forceinline__ Hit trace(const DevScene& sc, const float4* lds_tri, int lds_stride, const float* lds_num0,
-                                     vec3 o, vec3 d, int skip, bool live, bool shadow, float dist, bool all_primary,
-                                     LaneCounters& lc, WaveProf& wp) {
+__device__ __forceinline__ Hit trace_tree(const DevScene& sc, const float4* lds_tri, vec3 o, vec3 d, int skip, bool live, bool shadow, float dist,
+                                          LaneCounters& lc, WaveProf& wp) {
 	if constexpr (ACCEL == 2) {
 		return cast_ray_lbvh<COUNT>(sc, (int*)lds_tri, o, d, skip, live, shadow, dist, lc, wp);
-	} else if constexpr (ACCEL == 3) {
+	} else {
 		// packets: one walk of the tree per octant present in the wave (one pass for almost every wave)
 		const vec3 ds = make3(fabsf(d.x) < 1e-30f ? 1e-30f : d.x, fabsf(d.y) < 1e-30f ? 1e-30f : d.y, fabsf(d.z) < 1e-30f ? 1e-30f : d.z);
 		const bool near = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) < sc.far_guard;   // false for NaN too
@@ -753,7 +776,26 @@ __device__ __forceinline__ Hit trace(const DevScene& sc, const float4* lds_tri, 
 			if (mine) h = hp;
 		}
 		return h;
-		} else if constexpr (COUNT) {
+	}
+}
+
+template <int ACCEL, bool COUNT>
+__device__ __forceinline__ Hit trace(const DevScene& sc, const float4* lds_tri, int lds_stride, const float* lds_num0,
+                                     vec3 o, vec3 d, int skip, bool live, bool shadow, float dist, int li, bool all_primary,
+                                     LaneCounters& lc, WaveProf& wp) {
+	if constexpr (ACCEL == 2 || ACCEL == 3) {
+		// shadow rays of lights with a direction grid are answered from it; everything else walks the tree
+		if (sc.n_lgrid > 0 && __builtin_amdgcn_ballot_w64(live && shadow) != 0ull) {
+			Hit hg;
+			hg.t = 1e9f; hg.idx = -1; hg.p = make3(0.f, 0.f, 0.f);
+			const bool served = shadow_by_grids<COUNT>(sc, o, d, skip, live, shadow, dist, li, hg, lc, wp);
+			const bool rest = live && !served;
+			if (__builtin_amdgcn_ballot_w64(rest) == 0ull) return hg;
+			const Hit hw = trace_tree<ACCEL, COUNT>(sc, lds_tri, o, d, skip, rest, shadow, dist, lc, wp);
+			return served ? hg : hw;
+		}
+		return trace_tree<ACCEL, COUNT>(sc, lds_tri, o, d, skip, live, shadow, dist, lc, wp);
+	} else if constexpr (COUNT) {
 		// instrumented, reference-order loop: the counters follow Source.cpp's own short-circuits
 		return cast_ray_brute<true>(sc.planes, sc.stride, sc.n_tris, o, d, skip, live, lc);
 	} else {
@@ -893,6 +935,23 @@ __device__ __forceinline__ Hit trace_kind(const DevScene& sc, const float* lds_n
 	else return trace_brute<ACCEL, KIND>(sc, lds_num0, o, d, skip, live, dist, wp);
 }
 
+// The shadow ray of light `li` (wave-uniform) for the lockstep kernel: through the light's direction grid when the commit
+// made one (LBVH scenes, rt_lgrid.hip), through the tree or the brute-force loop otherwise.
+template <int ACCEL>
+__device__ __forceinline__ Hit trace_shadow(const DevScene& sc_arg, const float* lds_num0, int li, vec3 L, vec3 o, vec3 d, int skip, bool live, float dist, WaveProf& wp) {
+	if constexpr (ACCEL == 2 || ACCEL == 3) {
+		if (li < sc_arg.n_lgrid) {
+			const __attribute__((address_space(4))) LightGrid* G = (const __attribute__((address_space(4))) LightGrid*)(unsigned long long)(sc_arg.lgrid + li);
+			if (G->R > 0) {
+				LaneCounters lc = { 0, 0, 0, 0 };
+				if constexpr (ACCEL == 3) return grid_shadow<false>(scene_from_kernel_args(sc_arg), li, L, o, d, skip, live, dist, lc, wp);
+				else return grid_shadow<false>(sc_arg, li, L, o, d, skip, live, dist, lc, wp);
+			}
+		}
+	}
+	return trace_kind<ACCEL, RAY_SHADOW>(sc_arg, lds_num0, o, d, skip, live, dist, wp);
+}
+
 // Per-lane attribute fetch by hit index (shininess Source.cpp:570/575, normal :561, colour :489).
 template <int ACCEL>
 __device__ __forceinline__ float4 tri_plane(const DevScene& sc, const float4* lds_tri, int lds_stride, int plane, int idx) {
@@ -1013,7 +1072,7 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 
 		// ---- the one closest-hit loop ---------------------------------------------------------
 		const bool all_primary = __builtin_amdgcn_ballot_w64(live && stage != ST_PRIMARY) == 0;
-		const Hit h = trace<ACCEL, COUNT>(sc, s_tri, lds_stride, s_num0, o, d, skip, live, stage == ST_SHADOW, dist,
+		const Hit h = trace<ACCEL, COUNT>(sc, s_tri, lds_stride, s_num0, o, d, skip, live, stage == ST_SHADOW, dist, li,
 		                                  all_primary, lc, wp);
 		RT_PROF(wp, WP_ITER);
 		RT_STAMP(wp, 2);      // closest-hit search
@@ -1257,7 +1316,7 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 				const float s = sqrtf(dot(ray, ray));                        // magnitude(ray), Source.cpp:26-28
 				const float inv = 1.0f / s;                                  // glm::normalize: v * inversesqrt(dot(v,v))
 				const vec3 ld = ray * inv;
-				const Hit sh = trace_kind<ACCEL, RAY_SHADOW>(sc, s_num0, hp, ld, hidx, shade, s, wp);   // Source.cpp:473
+				const Hit sh = trace_shadow<ACCEL>(sc, s_num0, li, make3(L.x, L.y, L.z), hp, ld, hidx, shade, s, wp);   // Source.cpp:473
 				if (shade && (!(sh.idx >= 0) || sh.t > s)) {                 // Source.cpp:476
 					const float f = 1.0f / (s * s) * L.w;                    // Source.cpp:488
 					const float modify = div65025(f);                        // ... / 255.0 / 255.0f: binary64 divisions, rounded to binary32
@@ -1300,7 +1359,7 @@ __global__ void __launch_bounds__(256) cast_rays_kernel(DevScene sc, int n, cons
 	}
 	LaneCounters lc = { 0, 0, 0, 0 };
 	WaveProf wp = {};
-	const Hit h = trace<ACCEL, false>(sc, s_tri, lds_stride, nullptr, o, d, skip, live, false, 0.f, false, lc, wp);
+	const Hit h = trace<ACCEL, false>(sc, s_tri, lds_stride, nullptr, o, d, skip, live, false, 0.f, 0, false, lc, wp);
 	if (live) {
 		float* w = out6 + (size_t)r * 6;
 		w[0] = h.idx >= 0 ? 1.0f : 0.0f;
@@ -1345,6 +1404,12 @@ DevScene dev_scene(const rt_scene* s, const DeviceState& d) {
 	sc.traversal = s->traversal;
 	sc.kernel_kind = s->kernel_kind;
 	sc.per_lane_ok = d.per_lane_ok ? 1 : 0;
+	sc.lgrid = (const LightGrid*)d.lgrid;
+	sc.n_lgrid = d.n_lgrid;
+	sc.debug = 0;
+#ifdef RT_EXPERIMENT
+	{ static const int dbg = [] { const char* e = getenv("RT355_GRID_DEBUG"); return e ? atoi(e) : 0; }(); sc.debug = dbg; }   // timing experiments: parts of grid_shadow switched off (wrong frames)
+#endif
 	for (int k = 0; k < 3; k++) { sc.bb_lo[k] = d.bb_lo[k]; sc.bb_hi[k] = d.bb_hi[k]; }
 	return sc;
 }

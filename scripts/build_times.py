@@ -23,27 +23,29 @@ def timed(sc, cams, trs, w, h, depth, n=6):
     return ev0.elapsed_time(ev1) / n / fpl * 1e3
 
 
-desc = scenes.spheres(20, 4, 800, 800)
-sizes = ((800, 800, 32), (3840, 2160, 16)) if "--frames" in sys.argv else ()
-with api.Scene.from_desc(desc) as sc:
-    for q, name in ((api.BUILD_PLOC, "ploc"), (api.BUILD_FAST, "fast"), (api.BUILD_SAH, "sah")):
-        sc.set_build(q)
-        ms, wall = [], []
-        for _ in range(3):
-            t = time.perf_counter()
-            sc.commit(0, api.ACCEL_LBVH)
-            wall.append((time.perf_counter() - t) * 1e3)
-            ms.append(sc.build_ms(0))
-        nodes = sc.bvh(0)
-        e = np.concatenate([nodes[:, 3:6] - nodes[:, 0:3], nodes[:, 9:12] - nodes[:, 6:9]]).astype(np.float64)
-        lo = np.minimum(nodes[0, 0:3], nodes[0, 6:9]).astype(np.float64); hi = np.maximum(nodes[0, 3:6], nodes[0, 9:12]).astype(np.float64)
-        r = hi - lo
-        cost = (e[:, 0] * e[:, 1] + e[:, 1] * e[:, 2] + e[:, 2] * e[:, 0]).sum() / (r[0] * r[1] + r[1] * r[2] + r[2] * r[0])
-        line = "%-5s built by %d: build_ms %s, commit wall %s, cost %.3f, depths %s" % (
-            name, sc.build_kind(0), " ".join("%.2f" % x for x in ms), " ".join("%.1f" % x for x in wall), cost, sc.bvh_depth(0))
-        print(line, flush=True)
-        for (w, h, fpl) in sizes:
-            cams, trs = api.camera_sweep(fpl, desc.cam_pos, desc.cam_rot)
-            for mode, mname in ((api.TRAVERSAL_PER_LANE, "per lane"), (api.TRAVERSAL_PACKET, "packets")):
-                sc.set_traversal(mode)
-                print("   %dx%d %-9s %8.1f us/frame" % (w, h, mname, timed(sc, cams, trs, w, h, desc.depth)), flush=True)
+if __name__ == "__main__":
+    desc = scenes.spheres(20, 4, 800, 800)
+    sizes = ((800, 800, 32), (3840, 2160, 16)) if "--frames" in sys.argv else ()
+    with api.Scene.from_desc(desc) as sc:
+        for q, name in ((api.BUILD_PLOC, "ploc"), (api.BUILD_FAST, "fast"), (api.BUILD_SAH, "sah")):
+            sc.set_build(q)
+            ms, wall = [], []
+            for _ in range(3):
+                t = time.perf_counter()
+                sc.commit(0, api.ACCEL_LBVH)
+                wall.append((time.perf_counter() - t) * 1e3)
+                ms.append(sc.build_ms(0))
+            nodes = sc.bvh(0)
+            e = np.concatenate([nodes[:, 3:6] - nodes[:, 0:3], nodes[:, 9:12] - nodes[:, 6:9]]).astype(np.float64)
+            lo = np.minimum(nodes[0, 0:3], nodes[0, 6:9]).astype(np.float64); hi = np.maximum(nodes[0, 3:6], nodes[0, 9:12]).astype(np.float64)
+            r = hi - lo
+            cost = (e[:, 0] * e[:, 1] + e[:, 1] * e[:, 2] + e[:, 2] * e[:, 0]).sum() / (r[0] * r[1] + r[1] * r[2] + r[2] * r[0])
+            line = "%-5s built by %d: build_ms %s, commit wall %s, cost %.3f, depths %s" % (
+                name, sc.build_kind(0), " ".join("%.2f" % x for x in ms), " ".join("%.1f" % x for x in wall), cost, sc.bvh_depth(0))
+            print(line, flush=True)
+            for (w, h, fpl) in sizes:
+                cams, trs = api.camera_sweep(fpl, desc.cam_pos, desc.cam_rot)
+                for mode, mname in ((api.TRAVERSAL_PER_LANE, "per lane"), (api.TRAVERSAL_PACKET, "packets")):
+                    sc.set_traversal(mode)
+                    print("   %dx%d %-9s %8.1f us/frame" % (w, h, mname, timed(sc, cams, trs, w, h, desc.depth)), flush=True)
+
