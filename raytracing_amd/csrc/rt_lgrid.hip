@@ -45,7 +45,7 @@ namespace {
 typedef unsigned long long u64;
 
 #ifndef RT_LGRID_CELL
-#define RT_LGRID_CELL 0.6f          /* cell size in mean triangle sizes as seen from the light */
+#define RT_LGRID_CELL 0.3f          /* cell size in mean triangle sizes as seen from the light (102k triangles, 3840x2160 by packets: 0.6 231 us/frame, 0.4 219, 0.25 211, 0.15 209; entries 0.6M, 1.1M, 2.1M, 2.7M) */
 #endif
 #define RT_LGRID_R_MIN 16
 #define RT_LGRID_R_MAX 1024

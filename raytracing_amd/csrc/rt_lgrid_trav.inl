@@ -113,11 +113,21 @@ __device__ __forceinline__ Hit grid_shadow(const DevScene& sc, int li, vec3 L, v
 		const c4ptr hrec = c4ptr_of(sc.hoist);
 		const float eps_lo = RT_EPS_BELOW * (1.0f - RT_PREFILTER_REL);
 		lim_hi = lim + fabsf(lim) * RT_PREFILTER_REL;
-		for (int j = 0; j < sc.hoist_count; j++) {
-			const int i = G->hidx[j];
-			const bool want = lim >= 0.0f && ((hm >> j) & 1u) != 0u && G->hmind[j] <= far && i != skip;
-			if (__builtin_amdgcn_ballot_w64(want) == 0ull) continue;
-			packet_leaf<COUNT>(hrec.offset_floats((unsigned int)j * (RT_AOS_F4 * 4u)), i, o, d, skip, true, eps_lo, h, lim, lim_hi, lc, wp);
+		// the lanes of a tile nearly always share one mask: take a lane's mask as a scalar, walk its set bits, repeat for what is left
+		unsigned int left = lim >= 0.0f ? hm : 0u;
+		for (;;) {
+			const unsigned long long any = __builtin_amdgcn_ballot_w64(left != 0u);
+			if (any == 0ull) break;
+			unsigned int m = __builtin_amdgcn_readlane(left, __builtin_ctzll(any));
+			left &= ~m;
+			while (m != 0u) {
+				const int j = __builtin_ctz(m);
+				m &= m - 1u;
+				const int i = G->hidx[j];
+				const bool want = lim >= 0.0f && ((hm >> j) & 1u) != 0u && G->hmind[j] <= far && i != skip;
+				if (__builtin_amdgcn_ballot_w64(want) == 0ull) continue;
+				packet_leaf<COUNT>(hrec.offset_floats((unsigned int)j * (RT_AOS_F4 * 4u)), i, o, d, skip, true, eps_lo, h, lim, lim_hi, lc, wp);
+			}
 		}
 	}
 	return h;
