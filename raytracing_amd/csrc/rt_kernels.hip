@@ -1429,7 +1429,7 @@ static bool use_packets_cols(const DevScene& sc, const float col0[3], const floa
 	const float du = sqrtf(col0[0] * col0[0] + col0[1] * col0[1] + col0[2] * col0[2]) / (float)(width > 0 ? width : 1);
 	const float dv = sqrtf(col1[0] * col1[0] + col1[1] * col1[1] + col1[2] * col1[2]) / (float)(height > 0 ? height : 1);
 	const float footprint = 8.0f * 0.5f * (du + dv) * sc.packet_scale;
-	return footprint < 4.0f;
+	return footprint < 5.5f;
 }
 
 static int pick_tiles_per_wave(int accel, long long tiles) {
@@ -1475,8 +1475,10 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 	fp.blocks_per_frame = (unsigned int)blocks;
 	// LBVH: walk the tree once per wavefront ("packet") when an 8x8 tile of rays is coherent against the
 	// scene's triangles, per lane otherwise.  Footprint of a tile at the far side of the scene in units
-	// of the mean triangle size; measured on the 100k-triangle scene: packets win below ~5 (800x800: 4.6, +3 %; 1200: 3.1,
-	// 1.27x; 1600: 2.3, 1.4x; 2400: 1.5, 1.6x; 3840x2160: 1.3, 1.7x) and lose above (400x400: 9.2, 0.6x).
+	// of the mean triangle size; measured on the 100k-triangle scene (round 3: clustered tree, shadow rays through the light's
+	// grid, so only primary and bounce rays differ), us/frame packets | per lane: 300x300 (footprint 12.3) 17.6 | 7.7, 400 (9.2)
+	// 18.4 | 10.9, 500 (7.4) 20.4 | 15.5, 600 (6.1) 21.0 | 18.7, 800 (4.6) 26.4 | 29.0, 1000 (3.7) 34.3 | 41.6, 1200 (3.1) 44.4 | 55.9,
+	// 1600 (2.3) 67.9 | 90.5, 2400 (1.5) 127.5 | 183.5, 3840x2160 (1.3) 172.1 | 244.7: packets below a footprint of 5.5.
 	DevScene sc_sel = sc;
 	if (accel == RT_ACCEL_LBVH && !use_packets_cols(sc, fp.pose[0] + 3, fp.pose[0] + 6, fp.width, fp.height)) sc_sel.skip_count = 0;
 	dim3 grid((unsigned)(blocks * n_frames)), block((unsigned)threads);
