@@ -305,6 +305,18 @@ int         rt_scene_set_build(rt_scene* s, int quality);
 /* What really built the tree of the last LBVH commit on `device`: RT_BUILD_PLOC, _SAH or _FAST (a PLOC commit that
  * fell back reports FAST); RT_ERR_STATE for a brute-force commit.  No counterpart in the reference. */
 int         rt_scene_build_kind(const rt_scene* s, int device);
+/* Tuning knob of one scene: how the PRIMARY rays of an LBVH commit find their hit.  Pixels do not depend on it.  The primary rays of
+ * a frame (Src:534-548) all start at the camera, so a triangle can only be hit by the rays of the few pixels it projects onto.
+ * RASTER: before the render kernel a pass with one lane per (frame, triangle) projects each triangle of the tree onto the view plane,
+ * runs the reference's own test (Src:383-396) for the pixels inside the projected box and keeps, per pixel, the smallest (t, index)
+ * with a 64-bit atomic minimum; the render kernel reads its pixel's hit instead of walking the tree (bounce rays still walk it).
+ * Applies to whole frames with a near-orthonormal view matrix (rt_camera_trans gives one) and a camera within the scene's
+ * neighbourhood; other launches, and frames in which more than 32 triangles are too near the camera to project, walk the tree.
+ * WALK: always the tree.  AUTO (the default): RASTER for trees of 2048 triangles and more. */
+#define RT_PRIMARY_AUTO   0
+#define RT_PRIMARY_WALK   1
+#define RT_PRIMARY_RASTER 2
+int         rt_scene_set_primary_raster(rt_scene* s, int mode);
 /* Tuning knob of one scene: direction grids for the shadow rays of LBVH commits (1, the default: on; 0: off; takes effect
  * at the next rt_scene_commit, committed trees of the scene become stale).  Pixels do not depend on it.  processLighting's
  * rays (Src:470-476) all end at a light, so as seen from the light each is ONE direction: per light (the first

@@ -24,6 +24,7 @@ ACCEL_AUTO, ACCEL_BRUTE, ACCEL_LBVH = 0, 1, 2
 TRAVERSAL_AUTO, TRAVERSAL_PER_LANE, TRAVERSAL_PACKET = 0, 1, 2
 KERNEL_AUTO, KERNEL_STATE_MACHINE, KERNEL_LOCKSTEP = 0, 1, 2
 BUILD_FAST, BUILD_SAH, BUILD_PLOC = 0, 1, 2
+PRIMARY_AUTO, PRIMARY_WALK, PRIMARY_RASTER = 0, 1, 2
 STRICT = 0            # RT_RENDER_STRICT: the only render mode (bit-identical frames)
 OUT_RGBA8 = 0x100     # RT_OUT_RGBA8: the output buffer takes packed 8-bit pixels instead of three floats
 SHADE_GLSL = 0x200    # RT_SHADE_GLSL: the colour arithmetic of the reference's compute shader (Compute.shader:181-219, 330)
@@ -43,7 +44,7 @@ SYMBOLS = (
     "rt_camera_translate", "rt_camera_frame_time", "rt_camera_step", "rt_camera_path", "rt_render", "rt_render_device",
     "rt_render_frames_device", "rt_render_tiles_device", "rt_shard_rows", "rt_render_stats", "rt_render_multi", "rt_cast_rays",
     "rt_render_async", "rt_render_wait", "rt_frame_alloc", "rt_frame_free", "rt_cast_rays_noalloc",
-    "rt_device_count", "rt_device_props", "rt_scene_set_tiles_per_wave", "rt_scene_set_traversal", "rt_scene_set_kernel", "rt_scene_set_build", "rt_scene_build_kind", "rt_scene_set_shadow_grid", "rt_scene_shadow_grid", "rt_scene_traversal", "rt_last_error", "rt_version",
+    "rt_device_count", "rt_device_props", "rt_scene_set_tiles_per_wave", "rt_scene_set_traversal", "rt_scene_set_kernel", "rt_scene_set_build", "rt_scene_build_kind", "rt_scene_set_shadow_grid", "rt_scene_shadow_grid", "rt_scene_set_primary_raster", "rt_scene_traversal", "rt_last_error", "rt_version",
 )
 
 
@@ -156,6 +157,7 @@ def lib():
     L.rt_scene_set_build.argtypes = [vp, ci]
     L.rt_scene_build_kind.argtypes = [vp, ci]
     L.rt_scene_set_shadow_grid.argtypes = [vp, ci]
+    L.rt_scene_set_primary_raster.argtypes = [vp, ci]
     L.rt_scene_shadow_grid.argtypes = [vp, ci, ci, C.POINTER(ci), C.POINTER(C.c_longlong), C.POINTER(ci), C.POINTER(cf)]
     L.rt_scene_bvh_depth.argtypes = [vp, ci, C.POINTER(ci), C.POINTER(ci)]
     L.rt_render_async.argtypes = [vp, _fp, _fp, ci, ci, ci, ci, vp]
@@ -431,6 +433,11 @@ class Scene:
         locally-ordered clustering, all on the GPU), BUILD_FAST (Morton/Karras on the GPU) or BUILD_SAH (binned
         surface-area heuristic on host threads)."""
         _check(lib().rt_scene_set_build(self._h, int(quality)))
+        return self
+
+    def set_primary_raster(self, mode: int) -> "Scene":
+        """How primary rays of LBVH commits find their hit (rt_scene_set_primary_raster): PRIMARY_AUTO | _WALK | _RASTER."""
+        _check(lib().rt_scene_set_primary_raster(self._h, int(mode)))
         return self
 
     def set_shadow_grid(self, on: bool) -> "Scene":

@@ -73,6 +73,7 @@ void free_device_state(DeviceState& d) {
 		// frames in flight (rt_render_async) finish before anything they use goes away
 		if (d.render_stream) (void)hipStreamSynchronize(d.render_stream);
 		if (d.copy_stream) (void)hipStreamSynchronize(d.copy_stream);
+		for (auto& b : d.vis_bufs) { if (b.vis) (void)hipFree(b.vis); if (b.meta) (void)hipFree(b.meta); }
 		if (d.planes) (void)hipFree(d.planes);
 		if (d.lights) (void)hipFree(d.lights);
 		if (d.counters) (void)hipFree(d.counters);
@@ -87,6 +88,7 @@ void free_device_state(DeviceState& d) {
 		if (d.copy_stream) (void)hipStreamDestroy(d.copy_stream);
 		lbvh_free(d);
 		lgrid_free(d);
+		if (d.tri_skip) (void)hipFree(d.tri_skip);
 	}
 	if (prev >= 0) (void)hipSetDevice(prev);
 	d = DeviceState();
@@ -157,6 +159,59 @@ void fill_frame(rt_scene* s, FrameParams& fp, const float cam[3], const float tr
 	fp.rgba8 = 0;
 	fp.shade_glsl = 0;
 	fp.counters = nullptr;
+	fp.vis = nullptr;
+	fp.vis_stride = 0;
+	fp.vis_count = nullptr;
+	fp.vis_list = nullptr;
+	fp.vis_pad = 0.f;
+}
+
+// The primary-visibility pass (rt_vis.inl) for the frames of `fp`, where it applies: an LBVH commit, whole frames, the lockstep
+// kernel, near-orthonormal view matrices, cameras within far_guard.  Sets fp.vis* and queues the pass on `stream`; leaves
+// fp.vis null (the render kernel then walks the tree for primary rays as before) otherwise.
+int prepare_visibility(rt_scene* s, DeviceState& d, const DevScene& sc, FrameParams& fp, bool count, hipStream_t stream) {
+	if (d.accel != RT_ACCEL_LBVH || !d.tri_skip || s->primary_raster == RT_PRIMARY_WALK) return RT_OK;
+	const int tree_tris = sc.n_tris - (int)d.hoisted.size();
+	if (s->primary_raster == RT_PRIMARY_AUTO && tree_tris < RT_VIS_MIN_TRIS) return RT_OK;
+	if (fp.shade_glsl || s->kernel_kind == RT_KERNEL_STATE_MACHINE) return RT_OK;
+	if (!(fp.tile_stride == 1 && fp.tile_first == 0 && fp.local_rows == fp.height)) return RT_OK;
+	const int nf = fp.n_frames < 1 ? 1 : fp.n_frames;
+	for (int f = 0; f < nf; f++) {
+		const float* P = fp.pose[f];
+		double c0[3], c1[3], c2[3], big = 0.0;
+		for (int k = 0; k < 3; k++) { c0[k] = P[3 + k]; c1[k] = P[6 + k]; c2[k] = 2.0 * P[9 + k]; big = fmax(big, fabs((double)P[k])); }
+		if (!(big < (double)d.far_guard)) return RT_OK;
+		auto dt = [](const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+		const double tol = 1e-2;
+		if (!(fabs(dt(c0, c0) - 1.0) < tol && fabs(dt(c1, c1) - 1.0) < tol && fabs(dt(c2, c2) - 1.0) < tol &&
+		      fabs(dt(c0, c1)) < tol && fabs(dt(c0, c2)) < tol && fabs(dt(c1, c2)) < tol)) return RT_OK;
+		const double det = c0[0] * (c1[1] * c2[2] - c1[2] * c2[1]) - c0[1] * (c1[0] * c2[2] - c1[2] * c2[0]) + c0[2] * (c1[0] * c2[1] - c1[1] * c2[0]);
+		if (!(fabs(fabs(det) - 1.0) < 3.0 * tol)) return RT_OK;
+	}
+	const size_t pixels = (size_t)fp.width * (size_t)fp.height;
+	const size_t bytes = (size_t)nf * pixels * sizeof(unsigned long long);
+	if (bytes > ((size_t)8 << 30)) return RT_OK;
+	DeviceState::VisBuf* vb = nullptr;
+	for (auto& b : d.vis_bufs) if (b.stream == (void*)stream) vb = &b;
+	if (!vb) {
+		if (d.vis_bufs.size() >= 8) return RT_OK;                  // (a ninth stream on this device: its launches walk the tree)
+		try { d.vis_bufs.emplace_back(); } catch (...) { return RT_OK; }
+		vb = &d.vis_bufs.back();
+		vb->stream = (void*)stream;
+	}
+	if (!vb->meta) RT_HIP(hipMalloc(&vb->meta, (size_t)RT_MAX_FRAMES * (1 + RT_VIS_LIST_MAX) * sizeof(int)));
+	if (vb->vis_bytes < bytes) {
+		if (vb->vis) { RT_HIP(hipStreamSynchronize(stream)); (void)hipFree(vb->vis); vb->vis = nullptr; vb->vis_bytes = 0; }
+		hipError_t e = hipMalloc(&vb->vis, bytes);
+		if (e != hipSuccess) { (void)hipGetLastError(); return RT_OK; }     // no room for the buffer: the tree walk needs none
+		vb->vis_bytes = bytes;
+	}
+	fp.vis = (const unsigned long long*)vb->vis;
+	fp.vis_stride = (long long)pixels;
+	fp.vis_count = (const int*)vb->meta;
+	fp.vis_list = (const int*)vb->meta + RT_MAX_FRAMES;
+	fp.vis_pad = d.pad;
+	return launch_vis_raster(sc, fp, (const unsigned char*)d.tri_skip, count, stream);
 }
 
 int ensure_frame(DeviceState& d, size_t bytes) {
@@ -283,6 +338,13 @@ int rt_scene_set_shadow_grid(rt_scene* s, int on) {
 	return RT_OK;
 }
 
+int rt_scene_set_primary_raster(rt_scene* s, int mode) {
+	if (!s) { set_error("rt_scene_set_primary_raster: NULL scene"); return RT_ERR_INVALID; }
+	if (mode != RT_PRIMARY_AUTO && mode != RT_PRIMARY_WALK && mode != RT_PRIMARY_RASTER) { set_error("rt_scene_set_primary_raster: unknown mode %d", mode); return RT_ERR_INVALID; }
+	s->primary_raster = mode;
+	return RT_OK;
+}
+
 int rt_scene_shadow_grid(const rt_scene* s, int device, int light, int* cells_per_edge, long long* entries, int* always, float* build_ms) {
 	if (!s || light < 0) { set_error("rt_scene_shadow_grid: bad argument"); return RT_ERR_INVALID; }
 	auto it = s->dev.find(device);
@@ -380,6 +442,12 @@ int rt_scene_commit(rt_scene* s, int device, int accel_flags) {
 		if (d.far_guard > g) d.far_guard = g;
 		int rc = lbvh_build(s, d, nullptr);
 		if (rc != RT_OK) return rc;
+		{   // which triangles the tree does not hold (the visibility pass leaves them to the render kernel)
+			std::vector<unsigned char> skip((size_t)(n > 0 ? n : 1), 0);
+			for (int i : d.hoisted) skip[(size_t)i] = 1;
+			RT_HIP(hipMalloc(&d.tri_skip, skip.size()));
+			RT_HIP(hipMemcpy(d.tri_skip, skip.data(), skip.size(), hipMemcpyHostToDevice));
+		}
 		rc = lgrid_build(s, d, nullptr);
 		if (rc != RT_OK) return rc;
 	}
@@ -458,7 +526,10 @@ int rt_render_tiles_device(rt_scene* s, int device, const float cam_pos[3], cons
 	fp.out = d_out_compact;
 	fp.rgba8 = (render_flags & RT_OUT_RGBA8) ? 1 : 0;
 	fp.shade_glsl = (render_flags & RT_SHADE_GLSL) ? 1 : 0;
-	return launch_render(dev_scene(s, *d), fp, d->accel, RT_RENDER_STRICT, false, (hipStream_t)hip_stream);
+	const DevScene sc = dev_scene(s, *d);
+	rc = prepare_visibility(s, *d, sc, fp, false, (hipStream_t)hip_stream);
+	if (rc != RT_OK) return rc;
+	return launch_render(sc, fp, d->accel, RT_RENDER_STRICT, false, (hipStream_t)hip_stream);
 }
 
 int rt_render_frames_device(rt_scene* s, int device, int n_frames, const float* cam_pos3, const float* trans16,
@@ -490,6 +561,8 @@ int rt_render_frames_device(rt_scene* s, int device, int n_frames, const float* 
 		fp.out = d_out_rgb + (size_t)f0 * frame_stride_floats;
 		fp.rgba8 = rgba8 ? 1 : 0;
 		fp.shade_glsl = (render_flags & RT_SHADE_GLSL) ? 1 : 0;
+		rc = prepare_visibility(s, *d, sc, fp, false, (hipStream_t)hip_stream);
+		if (rc != RT_OK) return rc;
 		rc = launch_render(sc, fp, d->accel, RT_RENDER_STRICT, false, (hipStream_t)hip_stream);
 		if (rc != RT_OK) return rc;
 	}
@@ -558,7 +631,11 @@ int rt_render_stats(rt_scene* s, const float cam_pos[3], const float trans16[16]
 #ifdef RT_PROFILE
 	rc = launch_render(dev_scene(s, *d), fp, d->accel, RT_RENDER_STRICT, false, nullptr);   // wave-level tuning counters
 #else
-	rc = launch_render(dev_scene(s, *d), fp, d->accel, RT_RENDER_STRICT, true, nullptr);
+	{
+		const DevScene sc = dev_scene(s, *d);
+		rc = prepare_visibility(s, *d, sc, fp, true, nullptr);                              // (counted like the frame is rendered)
+		if (rc == RT_OK) rc = launch_render(sc, fp, d->accel, RT_RENDER_STRICT, true, nullptr);
+	}
 #endif
 	if (rc != RT_OK) return rc;
 	unsigned long long c[32];

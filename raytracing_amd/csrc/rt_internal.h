@@ -144,7 +144,16 @@ struct FrameParams {
 	int rgba8;              // RT_OUT_RGBA8: store_pixel (rt_kernels.hip)
 	int shade_glsl;         // RT_SHADE_GLSL: the compute shader's colour arithmetic (render_kernel only; the launcher picks it)
 	unsigned long long* counters;   // rt_stats as 10 x u64, or null
+	// Primary visibility of the launch's frames, resolved by the rasterising pass before the render kernel (rt_vis.inl), or null:
+	// vis[frame * vis_stride + pixel] = (bits of t : triangle index) of the closest hit among the tree's triangles, ~0 for none
+	const unsigned long long* vis;
+	long long vis_stride;
+	const int* vis_count;           // per frame: triangles the pass could not project (tested for every pixel); > RT_VIS_LIST_MAX: the frame walks the tree
+	const int* vis_list;            // RT_VIS_LIST_MAX per frame
+	float vis_pad;                  // the commit's pad (rt_lbvh.hip tri_box_padded)
 };
+#define RT_VIS_LIST_MAX 32
+#define RT_VIS_MIN_TRIS 2048    /* RT_PRIMARY_AUTO: trees of fewer triangles keep the walk (two more launches per frame batch do not pay) */
 
 // ---- host scene ------------------------------------------------------------------------------
 
@@ -171,6 +180,10 @@ struct DeviceState {
 	int bvh_root = 0;
 	int stride = 0;
 	float build_ms = 0.f;
+	void* tri_skip = nullptr;              // one byte per triangle: 1 = kept out of the tree (hoisted); LBVH commits
+	// buffers of the primary-visibility pass (rt_vis.inl), one set per stream that launches on this device
+	struct VisBuf { void* stream = nullptr; void* vis = nullptr; size_t vis_bytes = 0; void* meta = nullptr; };
+	std::vector<VisBuf> vis_bufs;
 	// per-light shadow grids (rt_lgrid.hip)
 	void* lgrid = nullptr;                 // n_lgrid LightGrid records
 	int n_lgrid = 0;
@@ -212,6 +225,7 @@ struct rt_scene {
 	int kernel_kind = RT_KERNEL_AUTO;     // rt_scene_set_kernel
 	int build = RT_BUILD_PLOC;            // rt_scene_set_build (takes effect at the next LBVH commit)
 	int shadow_grid = 1;                  // rt_scene_set_shadow_grid (takes effect at the next LBVH commit)
+	int primary_raster = RT_PRIMARY_AUTO; // rt_scene_set_primary_raster
 	int uv_w = -1, uv_h = -1;             // frame size the division-free u, v were last checked for (rt_api.cpp fill_frame)
 	bool uv_fast = false;
 };
@@ -240,6 +254,7 @@ DevScene dev_scene(const rt_scene* s, const DeviceState& d);
 bool use_packets(const DevScene& sc, const float trans16[16], int width, int height);   // the launcher's choice for an LBVH scene
 int launch_render(const DevScene& sc, const FrameParams& fp, int accel, int render_flags, bool count, hipStream_t stream);
 int launch_cast_rays(const DevScene& sc, int accel, int n, const float* d_rays7, float* d_out6, hipStream_t stream);
+int launch_vis_raster(const DevScene& sc, const FrameParams& fp, const unsigned char* d_skip, bool count, hipStream_t stream);   // rt_vis.inl
 
 // rt_lbvh.hip
 int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream);

@@ -527,7 +527,7 @@ __device__ __forceinline__ void hoisted_tests(const DevScene& sc, vec3 o, vec3 d
 			const vec3 nn = xyz(N4), p1 = xyz(P14);
 			const float t = dot(p1 - o, nn) / dot(d, nn);                           // Source.cpp:383
 			const lanemask visit = lanes(live) & lanes(i != skip);                  // Source.cpp:302
-			const lanemask cand = visit & lanes(t > RT_EPS_BELOW) & lanes(t < lim); // Source.cpp:385, 391
+			const lanemask cand = visit & lanes(t > RT_EPS_BELOW) & (lanes(t < lim) | (lanes(t == h.t) & lanes(i < h.idx))); // Source.cpp:385, 391; index order when a tree hit came first (rt_vis.inl)
 			if constexpr (COUNT) { lc.plane += lane_in(visit); lc.point += lane_in(visit) && !(t < 0.0f); lc.edge += lane_in(cand); }
 			if (cand == 0) continue;
 			const vec3 I = make3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);      // Source.cpp:389
@@ -891,8 +891,8 @@ __device__ __forceinline__ Hit trace_brute(const DevScene& sc_arg, const float* 
 
 // castRay over the LBVH by packets for ONE kind of ray (lockstep kernel): one walk per direction octant
 // present among the live lanes (one pass for almost every wave).  Same set-up as trace<3>.
-template <int KIND>
-__device__ __forceinline__ Hit trace_packet(const DevScene& sc_arg, vec3 o, vec3 d, int skip, bool live, float dist, WaveProf& wp) {
+template <int KIND, bool COUNT>
+__device__ __forceinline__ Hit trace_packet(const DevScene& sc_arg, vec3 o, vec3 d, int skip, bool live, float dist, LaneCounters& lc, WaveProf& wp) {
 	const DevScene sc = scene_from_kernel_args(sc_arg);
 	const vec3 ds = make3(fabsf(d.x) < 1e-30f ? 1e-30f : d.x, fabsf(d.y) < 1e-30f ? 1e-30f : d.y, fabsf(d.z) < 1e-30f ? 1e-30f : d.z);
 	const bool near = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) < sc.far_guard;   // false for NaN too
@@ -913,44 +913,50 @@ __device__ __forceinline__ Hit trace_packet(const DevScene& sc_arg, vec3 o, vec3
 	h.t = 1e9f;
 	h.idx = -1;
 	h.p = make3(0.f, 0.f, 0.f);
-	LaneCounters lc = { 0, 0, 0, 0 };
 	while (todo) {
 		const unsigned int oct = __builtin_amdgcn_readlane(lane_oct, __builtin_ctzll(todo));
 		const bool mine = live && lane_oct == oct;
 		todo &= ~__builtin_amdgcn_ballot_w64(mine);
 		RT_PROF(wp, WP_TRACE);
-		const Hit hp = cast_ray_packet<false>(sc, (int)oct, o, d, inv, oi, skip, mine ? lim : -1.0f, KIND == RAY_SHADOW, lc, wp);
+		const Hit hp = cast_ray_packet<COUNT>(sc, (int)oct, o, d, inv, oi, skip, mine ? lim : -1.0f, KIND == RAY_SHADOW, lc, wp);
 		if (mine) h = hp;
 	}
 	return h;
 }
 
-template <int ACCEL, int KIND>
-__device__ __forceinline__ Hit trace_kind(const DevScene& sc, const float* lds_num0, vec3 o, vec3 d, int skip, bool live, float dist, WaveProf& wp) {
-	if constexpr (ACCEL == 3) return trace_packet<KIND>(sc, o, d, skip, live, dist, wp);
-	else if constexpr (ACCEL == 2) {
-		LaneCounters lc = { 0, 0, 0, 0 };
-		return cast_ray_lbvh<false>(sc, (int*)lds_num0, o, d, skip, live, KIND == RAY_SHADOW, dist, lc, wp);   // (lds_num0: the workgroup's LDS, here the stacks)
+// COUNT (tree kernels only): the work counters of SURVEY 8d, as the state-machine kernel keeps them
+template <int ACCEL, int KIND, bool COUNT>
+__device__ __forceinline__ Hit trace_kind(const DevScene& sc, const float* lds_num0, vec3 o, vec3 d, int skip, bool live, float dist, LaneCounters& lc, WaveProf& wp) {
+	if constexpr (ACCEL == 3) return trace_packet<KIND, COUNT>(sc, o, d, skip, live, dist, lc, wp);
+	else if constexpr (ACCEL == 2) return cast_ray_lbvh<COUNT>(sc, (int*)lds_num0, o, d, skip, live, KIND == RAY_SHADOW, dist, lc, wp);   // (lds_num0: the workgroup's LDS, here the stacks)
+	else {
+		static_assert(!COUNT, "the brute-force counters follow the reference-order loop of the state-machine kernel");
+		return trace_brute<ACCEL, KIND>(sc, lds_num0, o, d, skip, live, dist, wp);
 	}
-	else return trace_brute<ACCEL, KIND>(sc, lds_num0, o, d, skip, live, dist, wp);
 }
 
 // The shadow ray of light `li` (wave-uniform) for the lockstep kernel: through the light's direction grid when the commit
 // made one (LBVH scenes, rt_lgrid.hip), through the tree or the brute-force loop otherwise.
-template <int ACCEL>
-__device__ __forceinline__ Hit trace_shadow(const DevScene& sc_arg, const float* lds_num0, int li, vec3 L, vec3 o, vec3 d, int skip, bool live, float dist, WaveProf& wp) {
+template <int ACCEL, bool COUNT>
+__device__ __forceinline__ Hit trace_shadow(const DevScene& sc_arg, const float* lds_num0, int li, vec3 L, vec3 o, vec3 d, int skip, bool live, float dist,
+                                            LaneCounters& lc, WaveProf& wp) {
 	if constexpr (ACCEL == 2 || ACCEL == 3) {
 		if (li < sc_arg.n_lgrid) {
 			const __attribute__((address_space(4))) LightGrid* G = (const __attribute__((address_space(4))) LightGrid*)(unsigned long long)(sc_arg.lgrid + li);
 			if (G->R > 0) {
-				LaneCounters lc = { 0, 0, 0, 0 };
-				if constexpr (ACCEL == 3) return grid_shadow<false>(scene_from_kernel_args(sc_arg), li, L, o, d, skip, live, dist, lc, wp);
-				else return grid_shadow<false>(sc_arg, li, L, o, d, skip, live, dist, lc, wp);
+				if constexpr (ACCEL == 3) return grid_shadow<COUNT>(scene_from_kernel_args(sc_arg), li, L, o, d, skip, live, dist, lc, wp);
+				else return grid_shadow<COUNT>(sc_arg, li, L, o, d, skip, live, dist, lc, wp);
 			}
 		}
 	}
-	return trace_kind<ACCEL, RAY_SHADOW>(sc_arg, lds_num0, o, d, skip, live, dist, wp);
+	return trace_kind<ACCEL, RAY_SHADOW, COUNT>(sc_arg, lds_num0, o, d, skip, live, dist, lc, wp);
 }
+
+} // namespace rt
+
+#include "rt_vis.inl"
+
+namespace rt {
 
 // Per-lane attribute fetch by hit index (shininess Source.cpp:570/575, normal :561, colour :489).
 template <int ACCEL>
@@ -1219,7 +1225,8 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 // PLAIN: a whole frame (no row tiles) whose u, v are division-free — the launcher's common case, compiled without the
 // row mapping and the slow forms of Source.cpp:534-535, whose wave-uniform conditions otherwise sit in spilled SGPRs
 // and are re-read for every tile.  Instantiated for packets only (launch_render).
-template <int ACCEL, bool PLAIN>
+// COUNT (tree kernels): the work counters of rt_render_stats, counted in the very traversal a frame gets.
+template <int ACCEL, bool PLAIN, bool COUNT = false>
 __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL == 3 ? RT_MIN_WAVES_PACKET : RT_MIN_WAVES)) render_lockstep_kernel(DevScene sc, FrameParams fp, int tiles_per_wave) {
 	extern __shared__ float4 s_tri[];
 	float* s_num0 = (float*)s_tri;
@@ -1257,6 +1264,18 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 #ifdef RT_PROFILE
 	wp.g = fp.counters;
 #endif
+	unsigned int ctr[CTR_N];
+#pragma unroll
+	for (int k = 0; k < CTR_N; k++) ctr[k] = 0;
+	LaneCounters lc = { 0, 0, 0, 0 };
+	// primary hits of the tree's triangles from the visibility pass (rt_vis.inl)?  >= 0: yes, with that many listed triangles to test per pixel
+	int vis_list_n = -1;
+	if constexpr (ACCEL == 2 || ACCEL == 3) {
+		if (fp.vis != nullptr) {
+			vis_list_n = __builtin_amdgcn_readfirstlane(fp.vis_count[frame]);
+			if (vis_list_n > RT_VIS_LIST_MAX) vis_list_n = -1;                  // too many triangles the pass could not project: this frame walks the tree
+		}
+	}
 	for (; tile < tile_end; tile++) {
 		const int x = tx * RT_TILE_W + lx, ly = ty * RT_TILE_H + lyi;
 		const bool inside = (x < fp.width) && (ly < fp.local_rows);
@@ -1265,11 +1284,15 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 		vec3 d;
 		if constexpr (PLAIN) d = primary_dir_plain(x, ly, fp, frame);
 		else d = primary_dir(x, global_row(ly, fp), fp, frame);
-		const Hit h = trace_kind<ACCEL, RAY_PRIMARY>(sc, s_num0, cam, d, -1, inside, 0.f, wp);
+		Hit h;
+		if (vis_list_n >= 0) h = trace_primary_vis<ACCEL == 3 ? 3 : 2, COUNT>(sc, fp, frame, vis_list_n, (long long)ly * fp.width + x, cam, d, inside, lc, wp);
+		else h = trace_kind<ACCEL, RAY_PRIMARY, COUNT>(sc, s_num0, cam, d, -1, inside, 0.f, lc, wp);
 		const bool hit = inside && h.idx >= 0;
+		if constexpr (COUNT) { ctr[CTR_PRIMARY] += inside; ctr[CTR_PXHIT] += hit; }
 		float4 A = make_float4(0.f, 0.f, 0.f, 0.f);                          // colour, shininess of the triangle to be lit
 		if (hit) A = sc.planes[PL_COL * sc.stride + h.idx];
 		bool bouncing = hit && A.w > 0.5f;                                   // Source.cpp:570
+		if constexpr (COUNT) ctr[CTR_PXMIRROR] += bouncing;
 		bool shade = hit && !bouncing;                                       // Source.cpp:597
 		vec3 hp = h.p;                                                       // what processLighting gets: hit.point, hit.cur
 		int hidx = h.idx;
@@ -1284,7 +1307,8 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 				bd = normalize(reflect(d, face_normal(d, xyz(N4))));         // Source.cpp:561, 572
 			}
 			while (__builtin_amdgcn_ballot_w64(bouncing) != 0ull) {
-				const Hit g = trace_kind<ACCEL, RAY_BOUNCE>(sc, s_num0, bo, bd, bskip, bouncing, 0.f, wp);   // Source.cpp:573, 578
+				if constexpr (COUNT) ctr[CTR_BOUNCE] += bouncing;
+				const Hit g = trace_kind<ACCEL, RAY_BOUNCE, COUNT>(sc, s_num0, bo, bd, bskip, bouncing, 0.f, lc, wp);   // Source.cpp:573, 578
 				const bool ghit = bouncing && g.idx >= 0;
 				float4 GA = make_float4(0.f, 0.f, 0.f, 0.f);
 				if (ghit) GA = sc.planes[PL_COL * sc.stride + g.idx];
@@ -1309,6 +1333,7 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 		}
 		// ---- processLighting (Source.cpp:460-494), one light at a time for the whole wave
 		vec3 color = make3(0.f, 0.f, 0.f);                                   // Source.cpp:462
+		bool lit_any = false;
 		if (__builtin_amdgcn_ballot_w64(shade) != 0ull) {
 			for (int li = 0; li < sc.n_lights; li++) {
 				const float4 L = lights[li];
@@ -1316,8 +1341,10 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 				const float s = sqrtf(dot(ray, ray));                        // magnitude(ray), Source.cpp:26-28
 				const float inv = 1.0f / s;                                  // glm::normalize: v * inversesqrt(dot(v,v))
 				const vec3 ld = ray * inv;
-				const Hit sh = trace_shadow<ACCEL>(sc, s_num0, li, make3(L.x, L.y, L.z), hp, ld, hidx, shade, s, wp);   // Source.cpp:473
+				if constexpr (COUNT) ctr[CTR_SHADOW] += shade;
+				const Hit sh = trace_shadow<ACCEL, COUNT>(sc, s_num0, li, make3(L.x, L.y, L.z), hp, ld, hidx, shade, s, lc, wp);   // Source.cpp:473
 				if (shade && (!(sh.idx >= 0) || sh.t > s)) {                 // Source.cpp:476
+					lit_any = true;
 					const float f = 1.0f / (s * s) * L.w;                    // Source.cpp:488
 					const float modify = div65025(f);                        // ... / 255.0 / 255.0f: binary64 divisions, rounded to binary32
 					color.x = color.x + modify * A.x;                        // Source.cpp:489
@@ -1334,11 +1361,16 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 			if (c.z > 1.0f) c.z = 1.0f;
 			store_pixel(fp, frame, (long long)ly * fp.width + x, c);        // (local rows)
 		}
+		if constexpr (COUNT) ctr[CTR_PXLIT] += lit_any;
 	}
 #ifdef RT_PROFILE
-	if (fp.counters != nullptr && (threadIdx.x & 63) == 0)
+	if (!COUNT && fp.counters != nullptr && (threadIdx.x & 63) == 0)
 		for (int k = 0; k < 10; k++) atomicAdd(&fp.counters[k], (unsigned long long)wp.v[k]);
 #endif
+	if constexpr (COUNT) {
+		ctr[CTR_PLANE] = lc.plane; ctr[CTR_POINT] = lc.point; ctr[CTR_EDGE] = lc.edge; ctr[CTR_BOX] = lc.box;
+		flush_counters<COUNT>(fp.counters, ctr);
+	}
 }
 
 // ---- castRay for a batch of rays (tests, tools) ----------------------------------------------
@@ -1455,7 +1487,8 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 	// 14.1 | 13.5 | 13.3 | 14.1, 1600x1600 - | - | 47.4 | 45.2, mirrors 3840x2160 255 | 242 | 236 | 233 | 239, room 7680x4320 653 | 613 | 585 | 567 | 573)
 	// AUTO is the lockstep form: measured faster than, or equal to, the state machine on every scene tried, up to
 	// depth 16 and with bounce depths that diverge inside a tile
-	const bool lockstep = !count && sc.kernel_kind != RT_KERNEL_STATE_MACHINE && !fp.shade_glsl;   // (RT_SHADE_GLSL lives in render_kernel only)
+	const bool lockstep_form = sc.kernel_kind != RT_KERNEL_STATE_MACHINE && !fp.shade_glsl;   // (RT_SHADE_GLSL lives in render_kernel only)
+	const bool lockstep = !count && lockstep_form;
 	int tpw = fp.tiles_per_wave > 0 ? fp.tiles_per_wave : (lockstep && accel != RT_ACCEL_LBVH ? (tiles * n_frames >= 128 * 8192 ? 2 * RT_LOCKSTEP_TILES : (tiles * n_frames >= 16 * 8192 ? RT_LOCKSTEP_TILES : (tiles * n_frames >= 4 * 8192 ? 2 : 1)))
 	                                                                                           : pick_tiles_per_wave(accel, tiles * n_frames));
 	// (tree kernels: one tile, except frames of 400k tiles and more — 102k triangles, measured 1 | 2 tiles: 3840x2160 214.6 | 222.7 us,
@@ -1506,7 +1539,10 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 	const bool plain = fp.uv_fast && fp.tile_stride == 1 && fp.tile_first == 0;
 	if (accel == RT_ACCEL_LBVH) {
 		const size_t lds = (size_t)RT_STACK_LDS * RT_STACK_PITCH * sizeof(int);   // [entry][lane]
-		if (count && sc_sel.skip_count > 0) hipLaunchKernelGGL((render_kernel<3, true>), grid, block, 0, stream, sc_sel, fp, tpw);   // the traversal the frame really gets
+		// (counting launches: in the kernel form and traversal the frame really gets)
+		if (count && sc_sel.skip_count > 0 && lockstep_form) hipLaunchKernelGGL((render_lockstep_kernel<3, false, true>), grid, block, 0, stream, sc_sel, fp, tpw);
+		else if (count && lockstep_form) hipLaunchKernelGGL((render_lockstep_kernel<2, false, true>), grid, block, lds, stream, sc_sel, fp, tpw);
+		else if (count && sc_sel.skip_count > 0) hipLaunchKernelGGL((render_kernel<3, true>), grid, block, 0, stream, sc_sel, fp, tpw);
 		else if (count) hipLaunchKernelGGL((render_kernel<2, true>), grid, block, lds, stream, sc_sel, fp, tpw);
 		else if (sc_sel.skip_count > 0 && lockstep && plain) hipLaunchKernelGGL((render_lockstep_kernel<3, true>), grid, block, 0, stream, sc_sel, fp, tpw);
 		else if (sc_sel.skip_count > 0 && lockstep) hipLaunchKernelGGL((render_lockstep_kernel<3, false>), grid, block, 0, stream, sc_sel, fp, tpw);
