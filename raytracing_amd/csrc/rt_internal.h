@@ -153,7 +153,6 @@ struct FrameParams {
 	float vis_pad;                  // the commit's pad (rt_lbvh.hip tri_box_padded)
 };
 #define RT_VIS_LIST_MAX 32
-#define RT_VIS_MIN_TRIS 2048    /* RT_PRIMARY_AUTO: trees of fewer triangles keep the walk (two more launches per frame batch do not pay) */
 
 // ---- host scene ------------------------------------------------------------------------------
 

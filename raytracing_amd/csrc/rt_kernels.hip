@@ -1292,6 +1292,9 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 		float4 A = make_float4(0.f, 0.f, 0.f, 0.f);                          // colour, shininess of the triangle to be lit
 		if (hit) A = sc.planes[PL_COL * sc.stride + h.idx];
 		bool bouncing = hit && A.w > 0.5f;                                   // Source.cpp:570
+#ifdef RT_EXPERIMENT
+		if (sc.debug & 8) bouncing = false;
+#endif
 		if constexpr (COUNT) ctr[CTR_PXMIRROR] += bouncing;
 		bool shade = hit && !bouncing;                                       // Source.cpp:597
 		vec3 hp = h.p;                                                       // what processLighting gets: hit.point, hit.cur

@@ -228,6 +228,9 @@ __device__ __forceinline__ Hit trace_primary_vis(const DevScene& sc_arg, const F
 			packet_leaf<COUNT>(aos.offset_floats((unsigned int)i * (RT_AOS_F4 * 4u)), i, o, d, -1, false, eps_lo, h, lim, lim_hi, lc, wp);
 		}
 	}
+#ifdef RT_EXPERIMENT
+	if (sc.debug & 4) return h;
+#endif
 	if (sc.hoist_count > 0) hoisted_tests<COUNT>(sc, o, d, inv, oi, -1, live, false, h, lim, lim_hi, lc, wp);
 	return h;
 }
