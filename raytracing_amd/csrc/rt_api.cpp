@@ -74,7 +74,7 @@ void free_device_state(DeviceState& d) {
 		// frames in flight (rt_render_async) finish before anything they use goes away
 		if (d.render_stream) (void)hipStreamSynchronize(d.render_stream);
 		if (d.copy_stream) (void)hipStreamSynchronize(d.copy_stream);
-		for (auto& b : d.vis_bufs) { if (b.vis) (void)hipFree(b.vis); if (b.meta) (void)hipFree(b.meta); }
+		for (auto& b : d.vis_bufs) { if (b.vis) (void)hipFree(b.vis); if (b.meta) (void)hipFree(b.meta); if (b.hmask) (void)hipFree(b.hmask); }
 		if (d.planes) (void)hipFree(d.planes);
 		if (d.lights) (void)hipFree(d.lights);
 		if (d.counters) (void)hipFree(d.counters);
@@ -165,6 +165,58 @@ void fill_frame(rt_scene* s, FrameParams& fp, const float cam[3], const float tr
 	fp.vis_count = nullptr;
 	fp.vis_list = nullptr;
 	fp.vis_pad = 0.f;
+	fp.hoist_mask = nullptr;
+	fp.hoist_cell_x = fp.hoist_cell_y = 0.f;
+}
+
+// This stream's scratch buffers on the device (visibility buffer, per-frame lists, hoisted-triangle masks); null when a ninth
+// stream asks (its launches then do without what the buffers are for).
+DeviceState::VisBuf* stream_scratch(DeviceState& d, hipStream_t stream) {
+	for (auto& b : d.vis_bufs) if (b.stream == (void*)stream) return &b;
+	if (d.vis_bufs.size() >= 8) return nullptr;
+	try { d.vis_bufs.emplace_back(); } catch (...) { return nullptr; }
+	d.vis_bufs.back().stream = (void*)stream;
+	return &d.vis_bufs.back();
+}
+
+// Per frame of the launch, which hoisted triangles a primary ray through each coarse cell of the view can meet (rt_vis.inl
+// hoist_mask_kernel): LBVH commits with hoisted triangles, the lockstep kernel, cameras within far_guard, invertible view matrices.
+int prepare_hoist_masks(rt_scene* s, DeviceState& d, const DevScene& sc, FrameParams& fp, hipStream_t stream) {
+	if (d.accel != RT_ACCEL_LBVH || d.hoist_count <= 0 || fp.shade_glsl || s->kernel_kind == RT_KERNEL_STATE_MACHINE) return RT_OK;
+	const int nf = fp.n_frames < 1 ? 1 : fp.n_frames;
+	for (int f = 0; f < nf; f++) {
+		const float* P = fp.pose[f];
+		double big = 0.0, c[3][3], n2 = 0.0;
+		for (int k = 0; k < 3; k++) {
+			big = fmax(big, fabs((double)P[k]));
+			c[0][k] = P[3 + k]; c[1][k] = P[6 + k]; c[2][k] = P[9 + k];
+			n2 += c[0][k] * c[0][k] + c[1][k] * c[1][k] + c[2][k] * c[2][k];
+		}
+		if (!(big < (double)d.far_guard)) return RT_OK;
+		const double det = c[0][0] * (c[1][1] * c[2][2] - c[1][2] * c[2][1]) - c[0][1] * (c[1][0] * c[2][2] - c[1][2] * c[2][0]) + c[0][2] * (c[1][0] * c[2][1] - c[1][1] * c[2][0]);
+		if (!(fabs(det) > 1e-3 * pow(n2 / 3.0, 1.5)) || !(n2 < 1e12)) return RT_OK;     // (a view matrix that is close to singular: the boxes, as before)
+	}
+	DeviceState::VisBuf* vb = stream_scratch(d, stream);
+	if (!vb) return RT_OK;
+	if (!vb->hmask) RT_HIP(hipMalloc(&vb->hmask, (size_t)RT_MAX_FRAMES * RT_HOIST_CELLS * RT_HOIST_CELLS * sizeof(unsigned int)));
+	fp.hoist_mask = (const unsigned int*)vb->hmask;
+	fp.hoist_cell_x = (float)RT_HOIST_CELLS / (float)fp.width;
+	fp.hoist_cell_y = (float)RT_HOIST_CELLS / (float)fp.height;
+	fp.vis_pad = d.pad;
+	int rc = launch_hoist_masks(sc, fp, stream);
+#ifdef RT_EXPERIMENT
+	if (rc == RT_OK && getenv("RT355_VIS_DEBUG")) {            // frame 0's masks: bits set per cell
+		unsigned int h[RT_HOIST_CELLS * RT_HOIST_CELLS];
+		(void)hipStreamSynchronize(stream);
+		(void)hipMemcpy(h, vb->hmask, sizeof h, hipMemcpyDeviceToHost);
+		fprintf(stderr, "hoist masks (%d hoisted):\n", d.hoist_count);
+		for (int v = 0; v < RT_HOIST_CELLS; v++) {
+			for (int u = 0; u < RT_HOIST_CELLS; u++) fprintf(stderr, " %2d", __builtin_popcount(h[v * RT_HOIST_CELLS + u]));
+			fprintf(stderr, "\n");
+		}
+	}
+#endif
+	return rc;
 }
 
 // The primary-visibility pass (rt_vis.inl) for the frames of `fp`, where it applies: an LBVH commit, whole frames, the lockstep
@@ -193,14 +245,8 @@ int prepare_visibility(rt_scene* s, DeviceState& d, const DevScene& sc, FramePar
 	const size_t pixels = (size_t)fp.width * (size_t)fp.height;
 	const size_t bytes = (size_t)nf * pixels * sizeof(unsigned long long);
 	if (bytes > ((size_t)8 << 30)) return RT_OK;
-	DeviceState::VisBuf* vb = nullptr;
-	for (auto& b : d.vis_bufs) if (b.stream == (void*)stream) vb = &b;
-	if (!vb) {
-		if (d.vis_bufs.size() >= 8) return RT_OK;                  // (a ninth stream on this device: its launches walk the tree)
-		try { d.vis_bufs.emplace_back(); } catch (...) { return RT_OK; }
-		vb = &d.vis_bufs.back();
-		vb->stream = (void*)stream;
-	}
+	DeviceState::VisBuf* vb = stream_scratch(d, stream);
+	if (!vb) return RT_OK;                                         // (a ninth stream on this device: its launches walk the tree)
 	if (!vb->meta) RT_HIP(hipMalloc(&vb->meta, (size_t)RT_MAX_FRAMES * (1 + RT_VIS_LIST_MAX) * sizeof(int)));
 	if (vb->vis_bytes < bytes) {
 		if (vb->vis) { RT_HIP(hipStreamSynchronize(stream)); (void)hipFree(vb->vis); vb->vis = nullptr; vb->vis_bytes = 0; }
@@ -540,6 +586,8 @@ int rt_render_tiles_device(rt_scene* s, int device, const float cam_pos[3], cons
 	fp.rgba8 = (render_flags & RT_OUT_RGBA8) ? 1 : 0;
 	fp.shade_glsl = (render_flags & RT_SHADE_GLSL) ? 1 : 0;
 	const DevScene sc = dev_scene(s, *d);
+	rc = prepare_hoist_masks(s, *d, sc, fp, (hipStream_t)hip_stream);
+	if (rc != RT_OK) return rc;
 	rc = prepare_visibility(s, *d, sc, fp, false, (hipStream_t)hip_stream);
 	if (rc != RT_OK) return rc;
 	return launch_render(sc, fp, d->accel, RT_RENDER_STRICT, false, (hipStream_t)hip_stream);
@@ -574,6 +622,8 @@ int rt_render_frames_device(rt_scene* s, int device, int n_frames, const float* 
 		fp.out = d_out_rgb + (size_t)f0 * frame_stride_floats;
 		fp.rgba8 = rgba8 ? 1 : 0;
 		fp.shade_glsl = (render_flags & RT_SHADE_GLSL) ? 1 : 0;
+		rc = prepare_hoist_masks(s, *d, sc, fp, (hipStream_t)hip_stream);
+		if (rc != RT_OK) return rc;
 		rc = prepare_visibility(s, *d, sc, fp, false, (hipStream_t)hip_stream);
 		if (rc != RT_OK) return rc;
 		rc = launch_render(sc, fp, d->accel, RT_RENDER_STRICT, false, (hipStream_t)hip_stream);
@@ -642,11 +692,16 @@ int rt_render_stats(rt_scene* s, const float cam_pos[3], const float trans16[16]
 	fp.out = (float*)d->frame;
 	fp.counters = (unsigned long long*)d->counters;
 #ifdef RT_PROFILE
-	rc = launch_render(dev_scene(s, *d), fp, d->accel, RT_RENDER_STRICT, false, nullptr);   // wave-level tuning counters
+	{
+		const DevScene sc = dev_scene(s, *d);
+		rc = prepare_hoist_masks(s, *d, sc, fp, nullptr);
+		if (rc == RT_OK) rc = launch_render(sc, fp, d->accel, RT_RENDER_STRICT, false, nullptr);   // wave-level tuning counters
+	}
 #else
 	{
 		const DevScene sc = dev_scene(s, *d);
-		rc = prepare_visibility(s, *d, sc, fp, true, nullptr);                              // (counted like the frame is rendered)
+		rc = prepare_hoist_masks(s, *d, sc, fp, nullptr);
+		if (rc == RT_OK) rc = prepare_visibility(s, *d, sc, fp, true, nullptr);             // (counted like the frame is rendered)
 		if (rc == RT_OK) rc = launch_render(sc, fp, d->accel, RT_RENDER_STRICT, true, nullptr);
 	}
 #endif

@@ -80,7 +80,8 @@ struct DevScene {
 	int skip_count;            // inner nodes per octant of the packet records (0: none)
 	// Wave-uniform ("packet") traversal of the same binary tree (rt_kernels.hip cast_ray_packet):
 	// per octant and inner node one 64-byte record with BOTH children, the one nearer along the
-	// octant first: (nearA.xyz, farA.xyz, refA, refB, nearB.xyz, farB.xyz, -, -).
+	// octant first: (nearA.xy, farA.xy, nearA.z, farA.z, refA, refB | nearB.xy, farB.xy, nearB.z, farB.z, -, -): the
+	// pairs a packed multiply-add takes (slab_hit_pk).
 	const float4* skiplist;
 	// Triangles whose box spans a large part of the scene (walls, a ground plane) are kept OUT of
 	// the tree, where each would inflate every box on its path to the root, and are tested first
@@ -151,7 +152,12 @@ struct FrameParams {
 	const int* vis_count;           // per frame: triangles the pass could not project (tested for every pixel); > RT_VIS_LIST_MAX: the frame walks the tree
 	const int* vis_list;            // RT_VIS_LIST_MAX per frame
 	float vis_pad;                  // the commit's pad (rt_lbvh.hip tri_box_padded)
+	// Which hoisted triangles a primary ray can meet, per frame and coarse cell of the view (rt_vis.inl hoist_mask_kernel), or null:
+	// hoist_mask[(frame * RT_HOIST_CELLS + cv) * RT_HOIST_CELLS + cu], cu = x * hoist_cell_x, cv = (global row) * hoist_cell_y
+	const unsigned int* hoist_mask;
+	float hoist_cell_x, hoist_cell_y;
 };
+#define RT_HOIST_CELLS 16
 #define RT_VIS_LIST_MAX 32
 
 // ---- host scene ------------------------------------------------------------------------------
@@ -181,7 +187,7 @@ struct DeviceState {
 	float build_ms = 0.f;
 	void* tri_skip = nullptr;              // one byte per triangle: 1 = kept out of the tree (hoisted); LBVH commits
 	// buffers of the primary-visibility pass (rt_vis.inl), one set per stream that launches on this device
-	struct VisBuf { void* stream = nullptr; void* vis = nullptr; size_t vis_bytes = 0; void* meta = nullptr; };
+	struct VisBuf { void* stream = nullptr; void* vis = nullptr; size_t vis_bytes = 0; void* meta = nullptr; void* hmask = nullptr; };
 	std::vector<VisBuf> vis_bufs;
 	// per-light shadow grids (rt_lgrid.hip)
 	void* lgrid = nullptr;                 // n_lgrid LightGrid records
@@ -253,6 +259,7 @@ DevScene dev_scene(const rt_scene* s, const DeviceState& d);
 bool use_packets(const DevScene& sc, const float trans16[16], int width, int height);   // the launcher's choice for an LBVH scene
 int launch_render(const DevScene& sc, const FrameParams& fp, int accel, int render_flags, bool count, hipStream_t stream);
 int launch_cast_rays(const DevScene& sc, int accel, int n, const float* d_rays7, float* d_out6, hipStream_t stream);
+int launch_hoist_masks(const DevScene& sc, const FrameParams& fp, hipStream_t stream);   // rt_vis.inl
 int launch_vis_raster(const DevScene& sc, const FrameParams& fp, const unsigned char* d_skip, bool count, hipStream_t stream);   // rt_vis.inl
 
 // rt_lbvh.hip

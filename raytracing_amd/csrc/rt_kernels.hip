@@ -285,6 +285,16 @@ __device__ __forceinline__ bool slab_hit_oct(float4 a, float4 b, vec3 inv, vec3 
 	                         __builtin_fmaf(a.w, inv.x, oi.x), __builtin_fmaf(b.x, inv.y, oi.y), __builtin_fmaf(b.y, inv.z, oi.z), lim_hi);
 }
 
+// The same test on a packet record (rt_lbvh.hip k_packet: near.x near.y far.x far.y | near.z far.z ref ref), the six
+// multiply-adds as three packed ones (v_pk_fma_f32: two lanes' worth of fma per issue slot, same results): ixy = (inv.x, inv.y),
+// izz = (inv.z, inv.z), likewise oxy, ozz.
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bool slab_hit_pk(float4 a, float4 b, f2v ixy, f2v izz, f2v oxy, f2v ozz, float lim_hi) {
+	const f2v nxy = { a.x, a.y }, fxy = { a.z, a.w }, zz = { b.x, b.y };
+	const f2v n = __builtin_elementwise_fma(nxy, ixy, oxy), f = __builtin_elementwise_fma(fxy, ixy, oxy), z = __builtin_elementwise_fma(zz, izz, ozz);
+	return slab_interval_hit(n.x, n.y, z.x, f.x, f.y, z.y, lim_hi);
+}
+
 // OCT: every live ray of the wave points into octant `oct` (bit k = component k negative).
 template <bool PRIMARY, bool OCT>
 __device__ __forceinline__ Hit cast_ray_pruned(const DevScene& sc, c4ptr tri, int oct, const float* num0, vec3 o, vec3 d,
@@ -376,8 +386,20 @@ __device__ __forceinline__ Hit cast_ray_pruned(const DevScene& sc, c4ptr tri, in
 // so ties go to the lower index explicitly (as in rt_lbvh_trav.inl).
 // COUNT: the work counters of SURVEY 8d for the lanes whose ray is still searching (lim >= 0) — what
 // the walk costs each ray it carries, in the units the per-lane traversal counts for itself.
-template <bool COUNT>
-__device__ __forceinline__ void packet_leaf(c4ptr T, int i, vec3 o, vec3 d, int skip, bool first_only,
+// A triangle record in LDS (the hoisted triangles, copied there per workgroup): the reads are broadcasts, the operands VGPRs
+struct l4ptr {
+	const float4* p;
+	__device__ __forceinline__ float4 operator[](unsigned int i) const { return p[i]; }
+};
+// How a trace handles the triangles kept out of the tree: behind their boxes (the default), or — by_mask — by the lanes' direction
+// masks hm (hoisted_by_mask), reading the records from the workgroup's LDS copy when there is one.
+struct HoistCtx {
+	unsigned int hm = 0xffffffffu;
+	bool by_mask = false;
+	const float4* lds = nullptr;     // hoist_count records of RT_AOS_F4 float4, then hoist_count triangle indices (ints)
+};
+template <bool COUNT, typename Rec>
+__device__ __forceinline__ void packet_leaf(Rec T, int i, vec3 o, vec3 d, int skip, bool first_only,
                                             float eps_lo, Hit& h, float& lim, float& lim_hi, LaneCounters& lc, WaveProf& wp) {
 	RT_PROF(wp, WP_TRI);
 	const float4 N4 = T[0], P14 = T[1];
@@ -421,9 +443,41 @@ __device__ __forceinline__ void wave_set_lane(int& v, int value, int lane) {
 	             : "+v"(v), "=&s"(m0_saved) : "s"(value), "s"(lane));
 }
 
+// The triangles kept out of the tree (DevScene::hoist) for rays whose direction cell says which of them they can meet: `hm` is the
+// lane's bit mask over the hoisted list (primary rays: FrameParams::hoist_mask, by the pixel's coarse cell of the view; rt_vis.inl
+// hoist_mask_kernel).  No box tests and no box records: the lanes of a tile nearly always share one mask — take one lane's mask as
+// a scalar, test the triangles of its set bits on the whole wave (the reference's arithmetic, ties to the lower index), repeat
+// with what other lanes still hold.  Lanes with lim < 0 are done.
+template <bool COUNT>
+__device__ __forceinline__ void hoisted_by_mask(const DevScene& sc, unsigned int hm, vec3 o, vec3 d, int skip, bool first_only,
+                                                Hit& h, float& lim, float& lim_hi, LaneCounters& lc, WaveProf& wp, const float4* lds = nullptr) {
+	const c4ptr hrec = c4ptr_of(sc.hoist);
+	const c4ptr hbox = hrec.offset_floats((unsigned int)sc.hoist_count * (RT_AOS_F4 * 4u));     // (octant 0's boxes: the second float4 of record j ends with the triangle's index)
+	const float eps_lo = RT_EPS_BELOW * (1.0f - RT_PREFILTER_REL);
+	unsigned int left = lim >= 0.0f ? hm : 0u;
+	for (;;) {
+		const unsigned long long any = __builtin_amdgcn_ballot_w64(left != 0u);
+		if (any == 0ull) break;
+		unsigned int m = __builtin_amdgcn_readlane(left, __builtin_ctzll(any));
+		left &= ~m;
+		while (m != 0u) {
+			const int j = __builtin_ctz(m);
+			m &= m - 1u;
+			if (j >= sc.hoist_count) break;
+			const int i = lds ? __builtin_amdgcn_readfirstlane(((const int*)(lds + sc.hoist_count * RT_AOS_F4))[j]) : __float_as_int(hbox[(unsigned int)j * 2u + 1u].w);
+			const bool want = lim >= 0.0f && ((hm >> j) & 1u) != 0u && i != skip;
+			if (__builtin_amdgcn_ballot_w64(want) == 0ull) continue;
+			RT_PROF(wp, WP_INBOX);
+			if (lds) { l4ptr R; R.p = lds + j * RT_AOS_F4; packet_leaf<COUNT>(R, i, o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp); }
+			else packet_leaf<COUNT>(hrec.offset_floats((unsigned int)j * (RT_AOS_F4 * 4u)), i, o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp);
+		}
+	}
+}
+
+// `by_mask` (wave-uniform): the hoisted triangles by the lanes' direction masks `hm` instead of behind their boxes
 template <bool COUNT>
 __device__ __forceinline__ Hit cast_ray_packet(const DevScene& sc, int oct, vec3 o, vec3 d, vec3 inv, vec3 oi,
-                                               int skip, float lim, bool first_only, LaneCounters& lc, WaveProf& wp) {
+                                               int skip, float lim, bool first_only, LaneCounters& lc, WaveProf& wp, HoistCtx hc = HoistCtx()) {
 	Hit h;
 	h.t = 1e9f;
 	h.idx = -1;
@@ -435,6 +489,7 @@ __device__ __forceinline__ Hit cast_ray_packet(const DevScene& sc, int oct, vec3
 #ifdef RT_PROFILE
 	int steps_ = 0;
 #endif
+	const f2v ixy = { inv.x, inv.y }, izz = { inv.z, inv.z }, oxy = { oi.x, oi.y }, ozz = { oi.z, oi.z };
 	int stackv = 0;          // wave-uniform stack: entry k lives in lane k (a Karras tree over 63 key bits is at most 63 deep)
 	int sp = 0;
 	int node = 0;
@@ -444,7 +499,7 @@ __device__ __forceinline__ Hit cast_ray_packet(const DevScene& sc, int oct, vec3
 		const int refA = __float_as_int(q1.z), refB = __float_as_int(q1.w);
 		RT_PROF(wp, WP_GROUP);
 		if constexpr (COUNT) lc.box += lim >= 0.0f;
-		const bool hitA = __builtin_amdgcn_ballot_w64(slab_hit_oct(q0, q1, inv, oi, lim_hi)) != 0;
+		const bool hitA = __builtin_amdgcn_ballot_w64(slab_hit_pk(q0, q1, ixy, izz, oxy, ozz, lim_hi)) != 0;
 		int next = -1;
 		if (hitA) {
 			if (refA < 0) packet_leaf<COUNT>(aos.offset_floats((unsigned int)(~refA) * (RT_AOS_F4 * 4u)), ~refA, o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp);
@@ -452,7 +507,7 @@ __device__ __forceinline__ Hit cast_ray_packet(const DevScene& sc, int oct, vec3
 		}
 		// the farther child is tested after a near LEAF has had its chance to shorten the limits
 		if constexpr (COUNT) lc.box += lim >= 0.0f;
-		const bool hitB = __builtin_amdgcn_ballot_w64(slab_hit_oct(q2, q3, inv, oi, lim_hi)) != 0;
+		const bool hitB = __builtin_amdgcn_ballot_w64(slab_hit_pk(q2, q3, ixy, izz, oxy, ozz, lim_hi)) != 0;
 		if (hitB) {
 			if (refB < 0) packet_leaf<COUNT>(aos.offset_floats((unsigned int)(~refB) * (RT_AOS_F4 * 4u)), ~refB, o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp);
 			else if (next >= 0) wave_set_lane(stackv, refB, sp++);
@@ -471,7 +526,12 @@ __device__ __forceinline__ Hit cast_ray_packet(const DevScene& sc, int oct, vec3
 	// The triangles kept out of the tree (DevScene::hoist), each behind its octant-ordered box — AFTER the walk: they are the
 	// scene-spanning ones (the walls of the reference's room), mostly behind what the tree holds, and with the limits the walk
 	// leaves their boxes are only met where a ray still has to reach them.
-	if (sc.hoist_count > 0 && __builtin_amdgcn_ballot_w64(lim >= 0.0f) != 0) {
+#ifdef RT_EXPERIMENT
+	if (sc.debug & 16) return h;
+#endif
+	if (hc.by_mask) {
+		if (sc.hoist_count > 0) hoisted_by_mask<COUNT>(sc, hc.hm, o, d, skip, first_only, h, lim, lim_hi, lc, wp, hc.lds);
+	} else if (sc.hoist_count > 0 && __builtin_amdgcn_ballot_w64(lim >= 0.0f) != 0) {
 		const c4ptr hrec = c4ptr_of(sc.hoist);
 		const c4ptr hbox = hrec.offset_floats((unsigned int)sc.hoist_count * (RT_AOS_F4 * 4u) + (unsigned int)oct * (unsigned int)sc.hoist_count * 8u);
 		for (int j = 0; j < sc.hoist_count;) {
@@ -892,7 +952,7 @@ __device__ __forceinline__ Hit trace_brute(const DevScene& sc_arg, const float* 
 // castRay over the LBVH by packets for ONE kind of ray (lockstep kernel): one walk per direction octant
 // present among the live lanes (one pass for almost every wave).  Same set-up as trace<3>.
 template <int KIND, bool COUNT>
-__device__ __forceinline__ Hit trace_packet(const DevScene& sc_arg, vec3 o, vec3 d, int skip, bool live, float dist, LaneCounters& lc, WaveProf& wp) {
+__device__ __forceinline__ Hit trace_packet(const DevScene& sc_arg, vec3 o, vec3 d, int skip, bool live, float dist, LaneCounters& lc, WaveProf& wp, HoistCtx hc = HoistCtx()) {
 	const DevScene sc = scene_from_kernel_args(sc_arg);
 	const vec3 ds = make3(fabsf(d.x) < 1e-30f ? 1e-30f : d.x, fabsf(d.y) < 1e-30f ? 1e-30f : d.y, fabsf(d.z) < 1e-30f ? 1e-30f : d.z);
 	const bool near = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) < sc.far_guard;   // false for NaN too
@@ -918,7 +978,7 @@ __device__ __forceinline__ Hit trace_packet(const DevScene& sc_arg, vec3 o, vec3
 		const bool mine = live && lane_oct == oct;
 		todo &= ~__builtin_amdgcn_ballot_w64(mine);
 		RT_PROF(wp, WP_TRACE);
-		const Hit hp = cast_ray_packet<COUNT>(sc, (int)oct, o, d, inv, oi, skip, mine ? lim : -1.0f, KIND == RAY_SHADOW, lc, wp);
+		const Hit hp = cast_ray_packet<COUNT>(sc, (int)oct, o, d, inv, oi, skip, mine ? lim : -1.0f, KIND == RAY_SHADOW, lc, wp, hc);
 		if (mine) h = hp;
 	}
 	return h;
@@ -926,9 +986,10 @@ __device__ __forceinline__ Hit trace_packet(const DevScene& sc_arg, vec3 o, vec3
 
 // COUNT (tree kernels only): the work counters of SURVEY 8d, as the state-machine kernel keeps them
 template <int ACCEL, int KIND, bool COUNT>
-__device__ __forceinline__ Hit trace_kind(const DevScene& sc, const float* lds_num0, vec3 o, vec3 d, int skip, bool live, float dist, LaneCounters& lc, WaveProf& wp) {
-	if constexpr (ACCEL == 3) return trace_packet<KIND, COUNT>(sc, o, d, skip, live, dist, lc, wp);
-	else if constexpr (ACCEL == 2) return cast_ray_lbvh<COUNT>(sc, (int*)lds_num0, o, d, skip, live, KIND == RAY_SHADOW, dist, lc, wp);   // (lds_num0: the workgroup's LDS, here the stacks)
+__device__ __forceinline__ Hit trace_kind(const DevScene& sc, const float* lds_num0, vec3 o, vec3 d, int skip, bool live, float dist, LaneCounters& lc, WaveProf& wp,
+                                          HoistCtx hc = HoistCtx()) {
+	if constexpr (ACCEL == 3) return trace_packet<KIND, COUNT>(sc, o, d, skip, live, dist, lc, wp, hc);
+	else if constexpr (ACCEL == 2) return cast_ray_lbvh<COUNT>(sc, (int*)lds_num0, o, d, skip, live, KIND == RAY_SHADOW, dist, lc, wp, hc);   // (lds_num0: the workgroup's LDS, here the stacks)
 	else {
 		static_assert(!COUNT, "the brute-force counters follow the reference-order loop of the state-machine kernel");
 		return trace_brute<ACCEL, KIND>(sc, lds_num0, o, d, skip, live, dist, wp);
@@ -939,13 +1000,13 @@ __device__ __forceinline__ Hit trace_kind(const DevScene& sc, const float* lds_n
 // made one (LBVH scenes, rt_lgrid.hip), through the tree or the brute-force loop otherwise.
 template <int ACCEL, bool COUNT>
 __device__ __forceinline__ Hit trace_shadow(const DevScene& sc_arg, const float* lds_num0, int li, vec3 L, vec3 o, vec3 d, int skip, bool live, float dist,
-                                            LaneCounters& lc, WaveProf& wp) {
+                                            LaneCounters& lc, WaveProf& wp, const float4* lds_hoist = nullptr) {
 	if constexpr (ACCEL == 2 || ACCEL == 3) {
 		if (li < sc_arg.n_lgrid) {
 			const __attribute__((address_space(4))) LightGrid* G = (const __attribute__((address_space(4))) LightGrid*)(unsigned long long)(sc_arg.lgrid + li);
 			if (G->R > 0) {
-				if constexpr (ACCEL == 3) return grid_shadow<COUNT>(scene_from_kernel_args(sc_arg), li, L, o, d, skip, live, dist, lc, wp);
-				else return grid_shadow<COUNT>(sc_arg, li, L, o, d, skip, live, dist, lc, wp);
+				if constexpr (ACCEL == 3) return grid_shadow<COUNT>(scene_from_kernel_args(sc_arg), li, L, o, d, skip, live, dist, lc, wp, lds_hoist);
+				else return grid_shadow<COUNT>(sc_arg, li, L, o, d, skip, live, dist, lc, wp, lds_hoist);
 			}
 		}
 	}
@@ -1230,6 +1291,9 @@ template <int ACCEL, bool PLAIN, bool COUNT = false>
 __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL == 3 ? RT_MIN_WAVES_PACKET : RT_MIN_WAVES)) render_lockstep_kernel(DevScene sc, FrameParams fp, int tiles_per_wave) {
 	extern __shared__ float4 s_tri[];
 	float* s_num0 = (float*)s_tri;
+	// (A copy of the hoisted triangles' records in LDS, read by broadcast instead of through the scalar cache, was measured SLOWER:
+	// 102k triangles 3840x2160 213.6 against 199.8 us/frame — the records then sit in vector registers the kernel does not have.)
+	const float4* lds_hoist = nullptr;
 	int frame = fp.n_frames > 1 ? (int)(blockIdx.x / fp.blocks_per_frame) : 0;      // workgroup-uniform
 	unsigned int block_in_frame = blockIdx.x - (unsigned int)frame * fp.blocks_per_frame;
 	if constexpr (ACCEL == 2 || ACCEL == 3) {
@@ -1285,8 +1349,18 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 		if constexpr (PLAIN) d = primary_dir_plain(x, ly, fp, frame);
 		else d = primary_dir(x, global_row(ly, fp), fp, frame);
 		Hit h;
-		if (vis_list_n >= 0) h = trace_primary_vis<ACCEL == 3 ? 3 : 2, COUNT>(sc, fp, frame, vis_list_n, (long long)ly * fp.width + x, cam, d, inside, lc, wp);
-		else h = trace_kind<ACCEL, RAY_PRIMARY, COUNT>(sc, s_num0, cam, d, -1, inside, 0.f, lc, wp);
+		HoistCtx hc;
+		hc.lds = lds_hoist;
+		if constexpr (ACCEL == 2 || ACCEL == 3) {
+			if (fp.hoist_mask != nullptr) {                                  // which hoisted triangles this pixel's direction can meet (rt_vis.inl)
+				hc.by_mask = true;
+				const int gy = PLAIN ? ly : global_row(ly, fp);
+				const int cu = min((int)((float)x * fp.hoist_cell_x), RT_HOIST_CELLS - 1), cv = min((int)((float)gy * fp.hoist_cell_y), RT_HOIST_CELLS - 1);
+				hc.hm = inside ? fp.hoist_mask[(frame * RT_HOIST_CELLS + cv) * RT_HOIST_CELLS + cu] : 0u;
+			}
+		}
+		if (vis_list_n >= 0) h = trace_primary_vis<ACCEL == 3 ? 3 : 2, COUNT>(sc, fp, frame, vis_list_n, (long long)ly * fp.width + x, cam, d, inside, lc, wp, hc);
+		else h = trace_kind<ACCEL, RAY_PRIMARY, COUNT>(sc, s_num0, cam, d, -1, inside, 0.f, lc, wp, hc);
 		const bool hit = inside && h.idx >= 0;
 		if constexpr (COUNT) { ctr[CTR_PRIMARY] += inside; ctr[CTR_PXHIT] += hit; }
 		float4 A = make_float4(0.f, 0.f, 0.f, 0.f);                          // colour, shininess of the triangle to be lit
@@ -1345,7 +1419,7 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 				const float inv = 1.0f / s;                                  // glm::normalize: v * inversesqrt(dot(v,v))
 				const vec3 ld = ray * inv;
 				if constexpr (COUNT) ctr[CTR_SHADOW] += shade;
-				const Hit sh = trace_shadow<ACCEL, COUNT>(sc, s_num0, li, make3(L.x, L.y, L.z), hp, ld, hidx, shade, s, lc, wp);   // Source.cpp:473
+				const Hit sh = trace_shadow<ACCEL, COUNT>(sc, s_num0, li, make3(L.x, L.y, L.z), hp, ld, hidx, shade, s, lc, wp, lds_hoist);   // Source.cpp:473
 				if (shade && (!(sh.idx >= 0) || sh.t > s)) {                 // Source.cpp:476
 					lit_any = true;
 					const float f = 1.0f / (s * s) * L.w;                    // Source.cpp:488
@@ -1542,15 +1616,16 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 	const bool plain = fp.uv_fast && fp.tile_stride == 1 && fp.tile_first == 0;
 	if (accel == RT_ACCEL_LBVH) {
 		const size_t lds = (size_t)RT_STACK_LDS * RT_STACK_PITCH * sizeof(int);   // [entry][lane]
+		const size_t lds_h = 0;
 		// (counting launches: in the kernel form and traversal the frame really gets)
-		if (count && sc_sel.skip_count > 0 && lockstep_form) hipLaunchKernelGGL((render_lockstep_kernel<3, false, true>), grid, block, 0, stream, sc_sel, fp, tpw);
-		else if (count && lockstep_form) hipLaunchKernelGGL((render_lockstep_kernel<2, false, true>), grid, block, lds, stream, sc_sel, fp, tpw);
+		if (count && sc_sel.skip_count > 0 && lockstep_form) hipLaunchKernelGGL((render_lockstep_kernel<3, false, true>), grid, block, lds_h, stream, sc_sel, fp, tpw);
+		else if (count && lockstep_form) hipLaunchKernelGGL((render_lockstep_kernel<2, false, true>), grid, block, lds + lds_h, stream, sc_sel, fp, tpw);
 		else if (count && sc_sel.skip_count > 0) hipLaunchKernelGGL((render_kernel<3, true>), grid, block, 0, stream, sc_sel, fp, tpw);
 		else if (count) hipLaunchKernelGGL((render_kernel<2, true>), grid, block, lds, stream, sc_sel, fp, tpw);
-		else if (sc_sel.skip_count > 0 && lockstep && plain) hipLaunchKernelGGL((render_lockstep_kernel<3, true>), grid, block, 0, stream, sc_sel, fp, tpw);
-		else if (sc_sel.skip_count > 0 && lockstep) hipLaunchKernelGGL((render_lockstep_kernel<3, false>), grid, block, 0, stream, sc_sel, fp, tpw);
+		else if (sc_sel.skip_count > 0 && lockstep && plain) hipLaunchKernelGGL((render_lockstep_kernel<3, true>), grid, block, lds_h, stream, sc_sel, fp, tpw);
+		else if (sc_sel.skip_count > 0 && lockstep) hipLaunchKernelGGL((render_lockstep_kernel<3, false>), grid, block, lds_h, stream, sc_sel, fp, tpw);
 		else if (sc_sel.skip_count > 0) hipLaunchKernelGGL((render_kernel<3, false>), grid, block, 0, stream, sc_sel, fp, tpw);
-		else if (lockstep) hipLaunchKernelGGL((render_lockstep_kernel<2, false>), grid, block, lds, stream, sc_sel, fp, tpw);
+		else if (lockstep) hipLaunchKernelGGL((render_lockstep_kernel<2, false>), grid, block, lds + lds_h, stream, sc_sel, fp, tpw);
 		else hipLaunchKernelGGL((render_kernel<2, false>), grid, block, lds, stream, sc_sel, fp, tpw);
 	} else if (sc.n_tris <= RT_LDS_MAX_TRIS) {
 		const size_t lds = (size_t)lds_stride_of(sc.n_tris) * sizeof(float);

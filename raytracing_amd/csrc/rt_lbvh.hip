@@ -322,12 +322,14 @@ __global__ void __launch_bounds__(256) k_packet(const float4* __restrict__ nodes
 		const bool neg_axis = (oct >> axis) & 1;
 		const int a = (left_lower != neg_axis) ? 0 : 1, b = 1 - a;
 		float v[16];
+		// per child: near.x near.y far.x far.y near.z far.z — the pairs the traversal's packed multiply-adds take as they lie
 		for (int k = 0; k < 3; k++) {
 			const bool neg = (oct >> k) & 1;
-			v[k] = neg ? hi[a][k] : lo[a][k];
-			v[3 + k] = neg ? lo[a][k] : hi[a][k];
-			v[8 + k] = neg ? hi[b][k] : lo[b][k];
-			v[11 + k] = neg ? lo[b][k] : hi[b][k];
+			const int at_near = k < 2 ? k : 4, at_far = k < 2 ? 2 + k : 5;
+			v[at_near] = neg ? hi[a][k] : lo[a][k];
+			v[at_far] = neg ? lo[a][k] : hi[a][k];
+			v[8 + at_near] = neg ? hi[b][k] : lo[b][k];
+			v[8 + at_far] = neg ? lo[b][k] : hi[b][k];
 		}
 		v[6] = __int_as_float(ref[a]);
 		v[7] = __int_as_float(ref[b]);

@@ -47,7 +47,7 @@ __device__ __forceinline__ void cswap(float& ka, int& ra, float& kb, int& rb) {
 
 template <bool COUNT>
 __device__ __forceinline__ Hit cast_ray_lbvh(const DevScene& sc, int* lds_stack, vec3 o, vec3 d, int skip, bool live,
-                                             bool shadow, float dist, LaneCounters& lc, WaveProf& wp) {
+                                             bool shadow, float dist, LaneCounters& lc, WaveProf& wp, HoistCtx hc = HoistCtx()) {
 	RT_PROF(wp, WP_TRACE);
 	Hit h;
 	h.t = 1e9f;                                                          // Source.cpp:278
@@ -71,7 +71,11 @@ __device__ __forceinline__ Hit cast_ray_lbvh(const DevScene& sc, int* lds_stack,
 	if (!cull) { s.inv = make3(0.f, 0.f, 0.f); s.oi = make3(0.f, 0.f, 0.f); }           // every (non-empty) box tests as hit
 	bool walk = live;
 	if (sc.hoist_count > 0) {
-		hoisted_tests<COUNT>(sc, o, d, s.inv, s.oi, skip, live, shadow, h, lim, lim_hi, lc, wp);
+		if (hc.by_mask) {                                                   // (rt_kernels.hip hoisted_by_mask: by the lanes' direction masks, no boxes)
+			float l2 = live ? lim : -1.0f, l2_hi = l2 + fabsf(l2) * RT_PREFILTER_REL;
+			hoisted_by_mask<COUNT>(sc, hc.hm, o, d, skip, shadow, h, l2, l2_hi, lc, wp, hc.lds);
+			if (live) { lim = l2; lim_hi = l2_hi; }
+		} else hoisted_tests<COUNT>(sc, o, d, s.inv, s.oi, skip, live, shadow, h, lim, lim_hi, lc, wp);
 		walk = live && lim >= 0.0f;                                      // a shadow ray that has its hit is done
 	}
 	const int SENT = 0x7fffffff;

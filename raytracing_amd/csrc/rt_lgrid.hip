@@ -180,11 +180,11 @@ int dev_alloc(T** p, size_t count) {
 } // namespace
 
 // Which hoisted triangles (kept out of the tree and out of the cell lists: walls, a ground plane) may be seen from the light in
-// each coarse direction cell: bit j of mask[(face * HC + v) * HC + u].  Conservative cone-against-box test on the host: the
-// cell's directions are the cone s*q_a > 0, u0 <= q_b / (s*q_a) <= u1, v0 <= q_c / (s*q_a) <= v1 — linear inequalities in
-// q = point - light — and a box all of whose corners break ONE of them lies outside the cone.  The box is the triangle's padded
-// box (widened a little more than the GPU's tri_box_padded, whose roundings this host copy does not share) and the cell is
-// widened by the same m as the cell lists' rectangles; a box nearer the light than S/250 is seen everywhere.
+// each coarse direction cell: bit j of mask[(face * HC + v) * HC + u].  On the host: the cell's directions are the cone
+// s*q_a >= 0, u0 <= q_b / (s*q_a) <= u1, v0 <= q_c / (s*q_a) <= v1 — linear inequalities in q = point - light — and the TRIANGLE
+// is clipped against them; what the reference can accept lies within the pad p of the triangle, so the cell is widened by the m
+// of the cell lists' rectangles plus the angle p / D stands for.  A triangle nearer the light than S/250, or so near that the
+// widening passes 0.1, is seen everywhere.
 void hoisted_masks(const rt_scene* s, const DeviceState& d, const float L[3], float S, std::vector<unsigned int>& mask, float* hmind, int* hidx) {
 	const int HC = RT_LGRID_HC;
 	mask.assign((size_t)6 * HC * HC, 0u);
@@ -212,28 +212,46 @@ void hoisted_masks(const rt_scene* s, const DeviceState& d, const float L[3], fl
 			hmind[j] = 0.f;
 			continue;
 		}
-		const double m = 4e-6 * S / D + 1e-4;
-		double q[8][3];
-		for (int c = 0; c < 8; c++) for (int k = 0; k < 3; k++) q[c][k] = ((c >> k) & 1 ? hi[k] : lo[k]) - L[k];
+		// hit points lie within p of the triangle: seen from the light an angle of at most p / D, at most twice that in face coordinates
+		const double m = 4e-6 * S / D + 1e-4 + 3.0 * p / D;
+		if (!(m < 0.1)) { for (unsigned int& w : mask) w |= 1u << j; hmind[j] = 0.f; continue; }
+		// The triangle clipped against each cell's cone (Sutherland-Hodgman, five planes through the light): a wall's BOX always has
+		// corners behind the face's plane, which no corner test can tell from corners inside the cone.
 		for (int f = 0; f < 6; f++) {
 			const int a = f >> 1, b = (a + 1) % 3, cc = (a + 2) % 3;
 			const double sg = (f & 1) ? -1.0 : 1.0;
+			double T[3][3];                                           // (q_b, q_c, s * q_a) of the three vertices
 			bool front = false;
-			for (int c = 0; c < 8; c++) front = front || sg * q[c][a] > 0.0;
+			for (int k = 0; k < 3; k++) {
+				T[k][0] = (double)v[3 * k + b] - L[b]; T[k][1] = (double)v[3 * k + cc] - L[cc]; T[k][2] = sg * ((double)v[3 * k + a] - L[a]);
+				front = front || T[k][2] > -p;
+			}
 			if (!front) continue;
 			for (int cv = 0; cv < HC; cv++)
 				for (int cu = 0; cu < HC; cu++) {
 					const double u0 = -1.0 + 2.0 * cu / HC - m, u1 = -1.0 + 2.0 * (cu + 1) / HC + m;
 					const double v0 = -1.0 + 2.0 * cv / HC - m, v1 = -1.0 + 2.0 * (cv + 1) / HC + m;
-					bool out_u0 = true, out_u1 = true, out_v0 = true, out_v1 = true;
-					for (int c = 0; c < 8; c++) {
-						const double qa = sg * q[c][a];
-						out_u0 = out_u0 && q[c][b] - u0 * qa < 0.0;
-						out_u1 = out_u1 && q[c][b] - u1 * qa > 0.0;
-						out_v0 = out_v0 && q[c][cc] - v0 * qa < 0.0;
-						out_v1 = out_v1 && q[c][cc] - v1 * qa > 0.0;
+					const double pl[5][3] = { { 0, 0, 1 }, { 1, 0, -u0 }, { -1, 0, u1 }, { 0, 1, -v0 }, { 0, -1, v1 } };
+					double P[10][3], Q[10][3];
+					int n = 3;
+					for (int k = 0; k < 3; k++) for (int e = 0; e < 3; e++) P[k][e] = T[k][e];
+					for (int c = 0; c < 5 && n > 0; c++) {
+						int k = 0;
+						for (int vtx = 0; vtx < n; vtx++) {
+							const int w = vtx + 1 == n ? 0 : vtx + 1;
+							const double fc = pl[c][0] * P[vtx][0] + pl[c][1] * P[vtx][1] + pl[c][2] * P[vtx][2];
+							const double fn = pl[c][0] * P[w][0] + pl[c][1] * P[w][1] + pl[c][2] * P[w][2];
+							if (fc >= 0.0 && k < 10) { for (int e = 0; e < 3; e++) Q[k][e] = P[vtx][e]; k++; }
+							if ((fc >= 0.0) != (fn >= 0.0) && k < 10) {
+								const double sgm = fc / (fc - fn);
+								for (int e = 0; e < 3; e++) Q[k][e] = P[vtx][e] + sgm * (P[w][e] - P[vtx][e]);
+								k++;
+							}
+						}
+						n = k;
+						for (int vtx = 0; vtx < n; vtx++) for (int e = 0; e < 3; e++) P[vtx][e] = Q[vtx][e];
 					}
-					if (!(out_u0 || out_u1 || out_v0 || out_v1)) mask[((size_t)f * HC + cv) * HC + cu] |= 1u << j;
+					if (n > 0) mask[((size_t)f * HC + cv) * HC + cu] |= 1u << j;
 				}
 		}
 	}

@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(256) vis_raster_kernel(DevScene sc, FrameParam
 // frame's list and the triangles kept out of the tree, ties to the lower index.  `pixel`: index into the frame (local rows).
 template <int ACCEL, bool COUNT>
 __device__ __forceinline__ Hit trace_primary_vis(const DevScene& sc_arg, const FrameParams& fp, int frame, int n_list, long long pixel, vec3 o, vec3 d, bool live,
-                                                 LaneCounters& lc, WaveProf& wp) {
+                                                 LaneCounters& lc, WaveProf& wp, HoistCtx hc) {
 	DevScene sc = sc_arg;
 	if constexpr (ACCEL == 3) sc = scene_from_kernel_args(sc_arg);
 	Hit h;
@@ -231,8 +231,139 @@ __device__ __forceinline__ Hit trace_primary_vis(const DevScene& sc_arg, const F
 #ifdef RT_EXPERIMENT
 	if (sc.debug & 4) return h;
 #endif
-	if (sc.hoist_count > 0) hoisted_tests<COUNT>(sc, o, d, inv, oi, -1, live, false, h, lim, lim_hi, lc, wp);
+	if (sc.hoist_count > 0) {
+		if (hc.by_mask) hoisted_by_mask<COUNT>(sc, hc.hm, o, d, -1, false, h, lim, lim_hi, lc, wp, hc.lds);
+		else hoisted_tests<COUNT>(sc, o, d, inv, oi, -1, live, false, h, lim, lim_hi, lc, wp);
+	}
 	return h;
+}
+
+// ---- the hoisted triangles by direction, for primary rays -------------------------------------------------------------------
+// The scene-spanning triangles kept out of the tree (DevScene::hoist: the walls of the reference's room) are what most primary rays
+// end on, and testing them behind their six boxes was the largest single item of a frame of the 102 412-triangle scene (measured:
+// 7.4 of 32 us at 800x800, 77 of 210 at 3840x2160).  Per frame of a launch this kernel marks, for each of RT_HOIST_CELLS x
+// RT_HOIST_CELLS cells of the view, which hoisted triangles a ray through the cell can meet at all — a cone-against-box test as
+// in rt_lgrid.hip hoisted_masks: the cell's rays are the cone t > 0, u0 <= a/t <= u1, v0 <= b/t <= v1 with (a, b, t) = M^-1 (P - camera),
+// linear inequalities in P; a padded box all of whose corners break one of them cannot be met.  The render kernel then tests
+// the one to three triangles of its pixel's cell (hoisted_by_mask) — no boxes.  Cells are widened by 2e-3 in u, v (far above the
+// roundings involved); a box nearer the camera than S/250 is marked everywhere.
+// One workgroup per frame: thread = (cell, one of RT_HOIST_GROUPS shares of the triangle list); most (cell, triangle) pairs end at
+// the first check — all three corners outside one of the cone's planes — and only the rest are clipped.
+#define RT_HOIST_GROUPS 4
+__global__ void __launch_bounds__(RT_HOIST_CELLS * RT_HOIST_CELLS * RT_HOIST_GROUPS) hoist_mask_kernel(DevScene sc, FrameParams fp, unsigned int* __restrict__ masks) {
+	__shared__ unsigned int s_mask[RT_HOIST_CELLS * RT_HOIST_CELLS];
+	const int frame = blockIdx.x;
+	const int cell = (int)threadIdx.x % (RT_HOIST_CELLS * RT_HOIST_CELLS), group = (int)threadIdx.x / (RT_HOIST_CELLS * RT_HOIST_CELLS);
+	const int cu = cell % RT_HOIST_CELLS, cv = cell / RT_HOIST_CELLS;
+	if (group == 0) s_mask[cell] = 0u;
+	__syncthreads();
+	const float* P = fp.pose[frame];
+	const vec3 cam = make3(P[0], P[1], P[2]);
+	const vec3 m0 = make3(P[3], P[4], P[5]), m1 = make3(P[6], P[7], P[8]), mc = make3(P[9], P[10], P[11]);
+	vec3 r0 = cross(m1, mc), r1 = cross(mc, m0), r2 = cross(m0, m1);
+	const float idet = 1.0f / dot(m0, r0);
+	r0 = r0 * idet; r1 = r1 * idet; r2 = r2 * idet;
+	const float m = 2e-3f, step = 1.0f / (float)RT_HOIST_CELLS;
+	const float u0 = -0.5f + step * (float)cu - m, u1 = -0.5f + step * (float)(cu + 1) + m;
+	const float v0 = -0.5f + step * (float)cv - m, v1 = -0.5f + step * (float)(cv + 1) + m;
+	float big = 0.f;
+	const float camv[3] = { cam.x, cam.y, cam.z };
+	for (int k = 0; k < 3; k++) big = fmaxf(big, fmaxf(fabsf(camv[k]), fmaxf(fabsf(sc.bb_lo[k]), fabsf(sc.bb_hi[k]))));
+	const float S = 4.0f * big;
+	unsigned int mask = 0u;
+	for (int j = group; j < sc.hoist_count && j < RT_HOIST_MAX; j += RT_HOIST_GROUPS) {
+		const float4* rec = sc.hoist + (size_t)j * RT_AOS_F4;
+		const float4 A = rec[1], B = rec[5], C = rec[6];
+		float lo[3], hi[3];
+		lo[0] = fminf(A.x, fminf(B.x, C.x)); hi[0] = fmaxf(A.x, fmaxf(B.x, C.x));
+		lo[1] = fminf(A.y, fminf(B.y, C.y)); hi[1] = fmaxf(A.y, fmaxf(B.y, C.y));
+		lo[2] = fminf(A.z, fminf(B.z, C.z)); hi[2] = fmaxf(A.z, fmaxf(B.z, C.z));
+		const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+		const float p = (fp.vis_pad * 0.1f + 1e-3f * sqrtf(dx * dx + dy * dy + dz * dz)) * 1.01f + 1e-6f * S;   // a little more than tri_box_padded
+		float d2 = 0.f;
+		for (int k = 0; k < 3; k++) {
+			lo[k] -= p; hi[k] += p;
+			const float dd = fmaxf(fmaxf(lo[k] - camv[k], camv[k] - hi[k]), 0.0f);
+			d2 += dd * dd;
+		}
+		const float D = sqrtf(d2);
+		// hit points lie within p of the triangle: seen from the camera that is an angle of at most p / D, about twice that in u, v
+		const float mj = m + 3.0f * p / D;
+		if (!(D * 250.0f > S) || !(mj < 0.05f)) { mask |= 1u << j; continue; }      // the camera is on or next to this triangle
+		// The triangle in (a, b, t) = M^-1 (P - camera) against the cell's cone t >= 0, u0 <= a/t <= u1, v0 <= b/t <= v1 — two convex
+		// cones from the origin, which meet unless a face plane of one has the other wholly outside (the separating-axis argument
+		// for the convex polygons they cut out of the plane t = 1, where the cell's is bounded).  The triangle's cone is that of
+		// its part with t >= 0: three or four rays after clipping at t = 0.  (A wall's BOX always has corners behind the camera,
+		// which no corner test can tell from corners inside the cone: hence the triangle itself.)
+		vec3 V[3];
+		{
+			const vec3 q0 = make3(A.x - cam.x, A.y - cam.y, A.z - cam.z), q1 = make3(B.x - cam.x, B.y - cam.y, B.z - cam.z), q2 = make3(C.x - cam.x, C.y - cam.y, C.z - cam.z);
+			V[0] = make3(dot(r0, q0), dot(r1, q0), dot(r2, q0));
+			V[1] = make3(dot(r0, q1), dot(r1, q1), dot(r2, q1));
+			V[2] = make3(dot(r0, q2), dot(r1, q2), dot(r2, q2));
+		}
+		const float U0 = u0 - mj + m, U1 = u1 + mj - m, W0 = v0 - mj + m, W1 = v1 + mj - m;      // (u0, u1, v0, v1 carry m already)
+		// (1) a face plane of the cell's cone with the whole triangle outside; or the triangle inside all of them
+		bool out = V[0].z < 0.f && V[1].z < 0.f && V[2].z < 0.f, in = V[0].z >= 0.f && V[1].z >= 0.f && V[2].z >= 0.f;
+		{
+			float f[3];
+			for (int k = 0; k < 3; k++) f[k] = V[k].x - U0 * V[k].z;
+			out = out || (f[0] < 0.f && f[1] < 0.f && f[2] < 0.f); in = in && f[0] >= 0.f && f[1] >= 0.f && f[2] >= 0.f;
+			for (int k = 0; k < 3; k++) f[k] = U1 * V[k].z - V[k].x;
+			out = out || (f[0] < 0.f && f[1] < 0.f && f[2] < 0.f); in = in && f[0] >= 0.f && f[1] >= 0.f && f[2] >= 0.f;
+			for (int k = 0; k < 3; k++) f[k] = V[k].y - W0 * V[k].z;
+			out = out || (f[0] < 0.f && f[1] < 0.f && f[2] < 0.f); in = in && f[0] >= 0.f && f[1] >= 0.f && f[2] >= 0.f;
+			for (int k = 0; k < 3; k++) f[k] = W1 * V[k].z - V[k].y;
+			out = out || (f[0] < 0.f && f[1] < 0.f && f[2] < 0.f); in = in && f[0] >= 0.f && f[1] >= 0.f && f[2] >= 0.f;
+		}
+		if (out) continue;
+		if (in) { mask |= 1u << j; continue; }
+		// (2) the rays of the triangle's part in front of the camera
+		vec3 Q[4];
+		int n = 3;
+		{
+			const int n_in = (V[0].z >= 0.f) + (V[1].z >= 0.f) + (V[2].z >= 0.f);       // 1..3 here
+			Q[0] = V[0]; Q[1] = V[1]; Q[2] = V[2]; Q[3] = V[0];
+			if (n_in < 3) {
+				// rotate so that the odd one out (the only vertex in front, or the only one behind) comes first
+				const bool want = n_in == 1;
+				const bool f0 = (V[0].z >= 0.f) == want, f1 = !f0 && (V[1].z >= 0.f) == want;
+				const vec3 X = f0 ? V[0] : (f1 ? V[1] : V[2]), Y = f0 ? V[1] : (f1 ? V[2] : V[0]), Z = f0 ? V[2] : (f1 ? V[0] : V[1]);
+				const float sy = X.z / (X.z - Y.z), sz = X.z / (X.z - Z.z);
+				const vec3 XY = make3(X.x + sy * (Y.x - X.x), X.y + sy * (Y.y - X.y), 0.f), XZ = make3(X.x + sz * (Z.x - X.x), X.y + sz * (Z.y - X.y), 0.f);
+				if (want) { Q[0] = X; Q[1] = XY; Q[2] = XZ; }
+				else { Q[0] = Y; Q[1] = Z; Q[2] = XZ; Q[3] = XY; n = 4; }
+			}
+		}
+		// (3) a face plane of the triangle's cone with the cell's four corner rays outside
+		bool apart = false;
+		auto face = [&](vec3 Pa, vec3 Pb, vec3 Pc) {
+			const vec3 nr = cross(Pa, Pb);
+			const float side = dot(nr, Pc), tol = 1e-4f * sqrtf(dot(nr, nr));
+			if (!(fabsf(side) > tol * (fabsf(Pc.x) + fabsf(Pc.y) + fabsf(Pc.z)))) return;     // (a degenerate face decides nothing)
+			const float sg = side > 0.f ? 1.f : -1.f;
+			const float c00 = sg * (nr.x * U0 + nr.y * W0 + nr.z), c10 = sg * (nr.x * U1 + nr.y * W0 + nr.z);
+			const float c01 = sg * (nr.x * U0 + nr.y * W1 + nr.z), c11 = sg * (nr.x * U1 + nr.y * W1 + nr.z);
+			const float lim = -2.0f * tol;
+			apart = apart || (c00 < lim && c10 < lim && c01 < lim && c11 < lim);
+		};
+		face(Q[0], Q[1], Q[2]);
+		face(Q[1], Q[2], n == 4 ? Q[3] : Q[0]);
+		if (n == 4) { face(Q[2], Q[3], Q[0]); face(Q[3], Q[0], Q[1]); }
+		else face(Q[2], Q[0], Q[1]);
+		if (!apart) mask |= 1u << j;
+	}
+	if (mask != 0u) atomicOr(&s_mask[cell], mask);
+	__syncthreads();
+	if (group == 0) masks[(size_t)frame * (RT_HOIST_CELLS * RT_HOIST_CELLS) + cell] = s_mask[cell];
+}
+
+int launch_hoist_masks(const DevScene& sc, const FrameParams& fp, hipStream_t stream) {
+	const int nf = fp.n_frames < 1 ? 1 : fp.n_frames;
+	hipLaunchKernelGGL(hoist_mask_kernel, dim3((unsigned int)nf), dim3(RT_HOIST_CELLS * RT_HOIST_CELLS * RT_HOIST_GROUPS), 0, stream, sc, fp, (unsigned int*)fp.hoist_mask);
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess) return hip_fail(e, "hoisted-triangle mask launch");
+	return RT_OK;
 }
 
 // Runs the pass for the frames of `fp` into fp.vis (set by the caller, with vis_stride, vis_count, vis_list): clears, rasterises.
