@@ -45,6 +45,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+from raytracing_amd.srchash import source_hash  # noqa: E402
+sys.path.insert(0, ROOT)
 
 PEAK_FP32_VALU_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 N_POSES = 64
@@ -128,6 +130,41 @@ def cpu_baseline(desc, seconds):
             "rays_per_frame": rays,
             "sample": "%d frames of the same %dx%d scene by oracle/rt_oracle.c (gcc -O2 -ffp-contract=off), "
                       "best frame, %.1f s of CPU" % (frames, desc.width, desc.height, wall)}
+
+
+def gpu_same_pose(api, torch, desc, dev, accel, frames=32, launches=4):
+    """The GPU on exactly the frame the CPU legs render — desc's own pose, `frames` copies of it per launch (the camera path of
+    the headline number visits other poses with other ray counts) -> ms per frame."""
+    cams = np.ascontiguousarray(np.tile(np.asarray(desc.cam_pos, dtype=np.float32), (frames, 1)))
+    trs = np.ascontiguousarray(np.tile(np.asarray(api.camera_trans(desc.cam_rot), dtype=np.float32).reshape(1, 16), (frames, 1)))
+    n = desc.width * desc.height * 3
+    buf = torch.empty(frames * n, dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with api.Scene.from_desc(desc) as sc:
+        sc.commit(dev, accel)
+        for _ in range(2):
+            sc.render_frames_device(dev, cams, trs, desc.width, desc.height, desc.depth, api.STRICT, buf.data_ptr(), n, st)
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(launches):
+            sc.render_frames_device(dev, cams, trs, desc.width, desc.height, desc.depth, api.STRICT, buf.data_ptr(), n, st)
+        ev1.record()
+        torch.cuda.synchronize()
+    return ev0.elapsed_time(ev1) / (launches * frames)
+
+
+def cpu_gpu_row(api, torch, desc, dev, accels, seconds, what):
+    """One BASELINE.md section-3 row: the reference's loop on one host thread and the GPU on the same frame (same pose, same size)."""
+    cb = cpu_baseline(desc, seconds)
+    row = {"what": what, "width": desc.width, "height": desc.height, "triangles": desc.n_triangles,
+           "cpu_baseline": cb}
+    for label, accel in accels:
+        ms = gpu_same_pose(api, torch, desc, dev, accel)
+        row["gpu_%s_ms_per_frame" % label] = ms
+        row["gpu_%s_Mrays_per_s" % label] = cb["rays_per_frame"] / ms / 1e3
+        row["gpu_%s_over_cpu_1thread" % label] = cb["rays_per_frame"] / ms / 1e3 / cb["value"]
+    return row
 
 
 def cpu_threaded(desc, threads):
@@ -262,16 +299,54 @@ def device_info(torch, dev):
     return dict(_DEVICE)
 
 
+# cycles per wave64 VALU instruction per SIMD, measured on this GPU (scripts/ubench/valu_forms.hip): FP32 add/mul/fma from
+# registers 2.5, the same with an SGPR operand 4.1 (the PMC mix cannot tell the two apart: low and high estimate); v_rcp/v_sqrt 8.2;
+# compares, selects, min/max, conversions, integer and lane ops 4.1
+CPI_ARITH_LOW, CPI_ARITH_HIGH, CPI_TRANS, CPI_OTHER = 2.5, 4.1, 8.2, 4.1
+SIMDS = 1024
+CLOCK_GHZ = 2.4
+
+
+def stamped(name, workload, key):
+    """profiles/<name>[workload][key] if that entry was measured on the sources this run uses (raytracing_amd/srchash.py), else None."""
+    e = read_profile_json(name).get(workload)
+    if not isinstance(e, dict) or e.get("source_hash") != source_hash():
+        return None
+    return e if key is None else e.get(key)
+
+
+def issue_use_of(workload, kernel_ms, fpl):
+    """Share of the SIMDs' vector issue slots the dominant kernel fills: VALU instructions per launch (rocprofv3 --pmc pass kept under
+    profiles/, same sources) priced at the measured cycles per instruction, over SIMDs x the kernel's cycles in THIS run."""
+    e = stamped("issue.json", workload, None)
+    if not e or not kernel_ms:
+        return None
+    k = fpl / float(e.get("frames_per_launch") or fpl)            # (the profiled launch may have held another number of frames)
+    arith, trans = e["valu_fp32_arith"] * k, e["valu_trans"] * k
+    other = e["valu"] * k - arith - trans
+    slots = SIMDS * kernel_ms * 1e-3 * CLOCK_GHZ * 1e9
+    low = (arith * CPI_ARITH_LOW + trans * CPI_TRANS + other * CPI_OTHER) / slots
+    high = (arith * CPI_ARITH_HIGH + trans * CPI_TRANS + other * CPI_OTHER) / slots
+    return {"low": low, "high": high, "valu_per_wave": e["valu"] / e["waves"], "salu_per_wave": e["salu"] / e["waves"],
+            "cycles_per_valu_if_issue_bound": slots / (e["valu"] * k),
+            "waves_resident_per_simd": e["wave_cycles_x4"] * 4.0 / (e["gui_active_all_xcds"] / 8.0 * SIMDS) if e.get("gui_active_all_xcds") else None,
+            "profile_round": e.get("round"), "kernel": e.get("kernel")}
+
+
 def roofline_of(flops_per_launch, kernel_ms, fpl, launches, workload):
     achieved = flops_per_launch / (kernel_ms * 1e-3) / 1e12
-    pmc = read_profile_json("traffic.json").get(workload)
-    issued = read_profile_json("issued.json").get(workload)
+    pmc = stamped("traffic.json", workload, "bytes_per_launch")
+    issued = stamped("issued.json", workload, "tflops")
+    stale = read_profile_json("issue.json").get(workload) is not None and stamped("issue.json", workload, None) is None
     return {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": pmc, "issued_tflops": issued,
+            "valu_issue_use": issue_use_of(workload, kernel_ms, fpl), "profile_source_hash": source_hash(), "profile_stale": stale,
             "kernel_ms": kernel_ms, "flops_per_launch": flops_per_launch, "frames_per_launch": fpl, "launches": launches,
             "note": "FP32 VALU roofline (SURVEY 8d): nothing here is HBM- or MFMA-shaped; algorithmic FLOPs = 14/plane + 6/point + "
-                    "17/edge term + 22/box + 32|29|30 per ray, counted in the traversal that is timed; issued_tflops = VALU FLOPs "
-                    "the kernel really executes per second (PMC pass under profiles/), secondary"}
+                    "17/edge term + 22/box + 32|29|30 per ray, counted in the traversal that is timed; valu_issue_use = share of the SIMDs' "
+                    "vector issue slots the kernel fills in this run (instruction counts of the PMC pass under profiles/ x measured cycles "
+                    "per instruction / (1024 SIMDs x kernel cycles)); issued_tflops = VALU FLOPs the kernel really executes per second; "
+                    "traffic, issued_tflops and valu_issue_use are null when profiles/ was measured on other sources (profile_stale)"}
 
 
 def side_config(api, torch, name, dev, args, launches=6, build=None):
@@ -292,6 +367,8 @@ def side_config(api, torch, name, dev, args, launches=6, build=None):
                "kernel_ms": kernel_ms, "kernel_ms_per_frame": kernel_ms / w.fpl,
                "roofline_frac": flops / launches / (kernel_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
                "flops_per_ray": flops / rays}
+        if build is None:
+            out["valu_issue_use"] = issue_use_of(name, kernel_ms, w.fpl)    # (profiles/ holds the default build's kernels)
         if w.accel_name == "lbvh":
             out["build"] = w.build
             out["build_where"] = "host threads (topology) + GPU (boxes, records)" if w.build == "sah" else "GPU"
@@ -430,7 +507,24 @@ def run_frames_mode(args, api, torch, dist, rank, world, dev, on_gpu, name):
             out["cpu_threaded"] = {"value": cb["rays_per_frame"] / mt / 1e6, "unit": "Mrays/s",
                                    "cores": threads, "kind": "port", "ms_per_frame": mt * 1e3,
                                    "sample": "row-interleaved pthreads over the same frame (stands in for the reference's disabled std::execution::par loop)"}
-            out["gpu_over_cpu_1thread"] = out["value"] / cb["value"]
+            # (the ratio on ONE frame: the CPU legs render the scene's own pose, so the GPU is timed on that pose too — the
+            # headline value averages a 64-pose path with other ray counts)
+            accel = api.ACCEL_LBVH if WORKLOADS[name][1] == "lbvh" else api.ACCEL_BRUTE
+            same_ms = gpu_same_pose(api, torch, w_desc, dev, accel)
+            out["gpu_same_pose"] = {"ms_per_frame": same_ms, "Mrays_per_s": cb["rays_per_frame"] / same_ms / 1e3,
+                                    "note": "32 copies per launch of the pose the cpu_baseline renders"}
+            out["gpu_over_cpu_1thread"] = out["gpu_same_pose"]["Mrays_per_s"] / cb["value"]
+            if not args.no_configs:
+                from raytracing_amd import scenes
+                rows = []
+                if True:
+                    rows.append(cpu_gpu_row(api, torch, scenes.room(400, 400), dev, (("brute", api.ACCEL_BRUTE),), min(args.cpu_seconds, 6.0),
+                                            "BASELINE config 1: the reference's room at 400x400 (Source.cpp:69-70 as shipped)"))
+                big = Workload._descs.get("spheres") or WORKLOADS["spheres800"][0](scenes)
+                rows.append(cpu_gpu_row(api, torch, big.with_size(64, 64), dev, (("lbvh", api.ACCEL_LBVH), ("brute", api.ACCEL_BRUTE)), 1.0,
+                                        "BASELINE config 4 at reduced size: 102 412 triangles, 64x64, the reference's loop over every triangle "
+                                        "(one frame is ~10 s of one host core; 800x800 would be ~25 min)"))
+                out["cpu_rows"] = rows
     return out
 
 

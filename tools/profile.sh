@@ -28,8 +28,11 @@ for w in $workloads; do
 done
 python3 - $out $tag $workloads <<'PY'
 import csv, sys, json, collections, glob, os
+sys.path.insert(0, os.getcwd())
+from raytracing_amd.srchash import source_hash
 out, tag = sys.argv[1], sys.argv[2]
-traffic, issued = {}, {}
+stamp = source_hash()                      # (what bench.py compares with the sources it runs: a profile of other code is not quoted)
+traffic, issued, issue = {}, {}, {}
 for w in sys.argv[3:]:
     # the dominant kernel of the run: the render kernel with the largest total time in the kernel trace
     # (room800: render_lockstep_kernel<0>; the tree scenes: <2> walked per lane or <3> by packets, as the launcher chose)
@@ -55,7 +58,9 @@ for w in sys.argv[3:]:
     fetch_kib, write_kib = summ.get("FETCH_SIZE", 0.0), summ.get("WRITE_SIZE", 0.0)
     summ["hbm_bytes_per_launch"] = {"fetch_raw": fetch_kib * 1024, "fetch_x2_gfx950": 2 * fetch_kib * 1024, "write": write_kib * 1024,
                                     "total_corrected": (2 * fetch_kib + write_kib) * 1024}
-    traffic[w] = summ["hbm_bytes_per_launch"]["total_corrected"]
+    traffic[w] = {"bytes_per_launch": summ["hbm_bytes_per_launch"]["total_corrected"], "write_bytes_per_launch": write_kib * 1024,
+                  "source_hash": stamp, "round": tag, "kernel": kern}
+    summ["source_hash"] = stamp
     wv = summ.get("SQ_WAVES", 1.0)
     summ["per_wave"] = {k: summ[k] / wv for k in summ if k.startswith("SQ_INSTS")}
     # issued VALU FLOPs: one per lane for add/mul/transcendental, two for fma, 64 lanes per wave instruction (an upper
@@ -65,11 +70,26 @@ for w in sys.argv[3:]:
                  + 2 * summ.get("SQ_INSTS_VALU_FMA_F64", 0))
     summ["issued_valu_flops_per_launch"] = fl
     if ns:
-        issued[w] = fl / (ns * 1e-9) / 1e12
-        summ["issued_valu_tflops"] = issued[w]
+        summ["issued_valu_tflops"] = fl / (ns * 1e-9) / 1e12
+        issued[w] = {"tflops": summ["issued_valu_tflops"], "source_hash": stamp, "round": tag, "kernel": kern}
+    # Vector issue slots: VALU instructions per launch by class, priced by bench.py with the issue rates
+    # measured on this GPU (scripts/ubench/valu_forms.hip: FP32 add/mul/fma 2.5 cycles per wave64 instruction from registers,
+    # 4.1 with an SGPR operand; transcendental 8.2; everything else 4.1) against SIMDs x the kernel's cycles of the LIVE run.
+    arith = summ.get("SQ_INSTS_VALU_ADD_F32", 0) + summ.get("SQ_INSTS_VALU_MUL_F32", 0) + summ.get("SQ_INSTS_VALU_FMA_F32", 0)
+    trans = summ.get("SQ_INSTS_VALU_TRANS_F32", 0)
+    try:
+        fpl = json.loads(open(os.path.join(out, "pmc_%s_3.json" % w)).read().strip().splitlines()[-1])["config"]["frames_per_step"]
+    except Exception:
+        fpl = None
+    issue[w] = {"frames_per_launch": fpl, "valu": summ.get("SQ_INSTS_VALU", 0), "valu_fp32_arith": arith, "valu_trans": trans, "salu": summ.get("SQ_INSTS_SALU", 0),
+                "smem": summ.get("SQ_INSTS_SMEM", 0), "waves": wv, "wave_cycles_x4": summ.get("SQ_WAVE_CYCLES", 0),
+                "gui_active_all_xcds": summ.get("GRBM_GUI_ACTIVE", 0), "kernel_ns_under_trace": ns,
+                "source_hash": stamp, "round": tag, "kernel": kern}
+    summ["issue"] = issue[w]
     json.dump(summ, open(os.path.join(out, "%s_%s_pmc.json" % (tag, w)), "w"), indent=1)
     print(w, json.dumps(summ, indent=1))
 json.dump(traffic, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 json.dump(issued, open(os.path.join(out, "issued.json"), "w"), indent=1)
+json.dump(issue, open(os.path.join(out, "issue.json"), "w"), indent=1)
 PY
 for w in $workloads; do cut -c1-200 $out/${tag}_${w}_kernel_stats.csv | head -8; done
