@@ -227,6 +227,22 @@ int rt_render_tiles_device(rt_scene* s, int device, const float cam_pos[3], cons
                            int tile_rows, int tile_first, int tile_stride,
                            float* d_out_compact, void* hip_stream);
 int rt_shard_rows(int height, int tile_rows, int tile_first, int tile_stride);
+/* The same shard into HOST memory, synchronous (launch on the scene's device, copy back): for exchanges whose transport
+ * takes host buffers (MPI or gloo without GPU-aware transport).  out_compact has rt_shard_rows() x width pixels. */
+int rt_render_tiles(rt_scene* s, const float cam_pos[3], const float trans16[16], int width, int height, int max_bounces,
+                    int render_flags, int tile_rows, int tile_first, int tile_stride, float* out_compact);
+
+/* The exchange step's other half: after the gather, the rank that displays the frame holds every rank's
+ * compact shard — shard r (tiles r, r + n_shards, ...: rt_render_tiles_device with tile_first = r, tile_stride =
+ * n_shards) at d_shards + r * pitch_bytes — and needs the reference's framebuffer, row y at y * width pixels
+ * (Src:550 `data[(y*w+x)*3+c]`, uploaded by Src:1270).  One kernel on `hip_stream` of `device` moves every row to its
+ * place (16 bytes per lane where sizes and addresses allow).  render_flags says what a pixel is: 3 floats, or 4 bytes
+ * with RT_OUT_RGBA8.  pitch_bytes: a multiple of 4, at least the size of shard 0 (the largest).  Asynchronous.
+ * rt_scatter_shards_host is the same on host memory (one memcpy per tile). */
+int rt_scatter_shards(int device, const void* d_shards, size_t pitch_bytes, int n_shards, int width, int height,
+                      int tile_rows, int render_flags, void* d_frame, void* hip_stream);
+int rt_scatter_shards_host(const void* shards, size_t pitch_bytes, int n_shards, int width, int height,
+                           int tile_rows, int render_flags, void* frame);
 
 /* The hand-off to the viewer (Src:1270 uploads `data` every frame) without stalling the render:
  * rt_render_async launches the frame on the scene's own render stream into one of two device frames
@@ -248,8 +264,11 @@ int rt_render_stats(rt_scene* s, const float cam_pos[3], const float trans16[16]
                     int height, int max_bounces, float* out_rgb /* may be NULL */, rt_stats* out);
 
 /* One process, several GPUs: commits the scene to devices[0..n) if needed, renders interleaved
- * row tiles on each (tile t -> devices[t % n]), gathers the shards into the frame on devices[0]
- * with peer-to-peer copies (xGMI) and copies it to host memory once from there. */
+ * row tiles on each (tile t -> devices[t % n]), gathers the compact shards on devices[0] with ONE
+ * peer-to-peer copy per device (xGMI), de-interleaves them there (rt_scatter_shards' kernel) and copies
+ * the frame to host memory once.  render_flags may carry RT_OUT_RGBA8 (out_rgb then receives width*height
+ * 4-byte pixels: a third of the bytes on every link) and RT_SHADE_GLSL.  A device may be listed more than
+ * once (it renders those shards one after the other): the N-GPU tile assignment rehearsed on fewer GPUs. */
 int rt_render_multi(rt_scene* s, const int* devices, int n_devices, const float cam_pos[3],
                     const float trans16[16], int width, int height, int max_bounces,
                     int render_flags, int tile_rows, float* out_rgb);

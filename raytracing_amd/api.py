@@ -42,7 +42,7 @@ SYMBOLS = (
     "rt_scene_triangle_count", "rt_scene_light_count", "rt_scene_get_triangles", "rt_scene_commit",
     "rt_scene_build_ms", "rt_scene_get_bvh", "rt_scene_get_hoisted", "rt_scene_accel", "rt_scene_bvh_depth", "rt_camera_trans", "rt_camera_init", "rt_camera_rotate",
     "rt_camera_translate", "rt_camera_frame_time", "rt_camera_step", "rt_camera_path", "rt_render", "rt_render_device",
-    "rt_render_frames_device", "rt_render_tiles_device", "rt_shard_rows", "rt_render_stats", "rt_render_multi", "rt_cast_rays",
+    "rt_render_frames_device", "rt_render_tiles_device", "rt_shard_rows", "rt_render_tiles", "rt_scatter_shards", "rt_scatter_shards_host", "rt_render_stats", "rt_render_multi", "rt_cast_rays",
     "rt_render_async", "rt_render_wait", "rt_frame_alloc", "rt_frame_free", "rt_cast_rays_noalloc",
     "rt_device_count", "rt_device_props", "rt_scene_set_tiles_per_wave", "rt_scene_set_traversal", "rt_scene_set_kernel", "rt_scene_set_build", "rt_scene_build_kind", "rt_scene_set_shadow_grid", "rt_scene_shadow_grid", "rt_scene_set_primary_raster", "rt_scene_traversal", "rt_last_error", "rt_version",
 )
@@ -146,6 +146,9 @@ def lib():
     L.rt_render_tiles_device.argtypes = [vp, ci, _fp, _fp, ci, ci, ci, ci, ci, ci, ci, vp, vp]
     L.rt_render_frames_device.argtypes = [vp, ci, ci, _fp, _fp, ci, ci, ci, ci, vp, C.c_size_t, vp]
     L.rt_shard_rows.argtypes = [ci, ci, ci, ci]
+    L.rt_render_tiles.argtypes = [vp, _fp, _fp, ci, ci, ci, ci, ci, ci, ci, vp]
+    L.rt_scatter_shards.argtypes = [ci, vp, C.c_size_t, ci, ci, ci, ci, ci, vp, vp]
+    L.rt_scatter_shards_host.argtypes = [vp, C.c_size_t, ci, ci, ci, ci, ci, vp]
     L.rt_render_stats.argtypes = [vp, _fp, _fp, ci, ci, ci, _fp, C.POINTER(Stats)]
     L.rt_render_multi.argtypes = [vp, C.POINTER(ci), ci, _fp, _fp, ci, ci, ci, ci, ci, _fp]
     L.rt_cast_rays.argtypes = [vp, ci, _fp, _fp]
@@ -239,6 +242,21 @@ def camera_trans(rot_deg: Sequence[float]) -> np.ndarray:
 
 def shard_rows(height: int, tile_rows: int, tile_first: int, tile_stride: int) -> int:
     return int(lib().rt_shard_rows(height, tile_rows, tile_first, tile_stride))
+
+
+def scatter_shards(device: int, d_shards_ptr: int, pitch_bytes: int, n_shards: int, width: int, height: int, tile_rows: int,
+                   mode: int, d_frame_ptr: int, stream: int = 0) -> None:
+    """rt_scatter_shards: de-interleave the gathered compact shards (shard r at d_shards_ptr + r*pitch_bytes) into the
+    frame at d_frame_ptr, one kernel on `stream` of `device`.  `mode` tells the pixel format (OUT_RGBA8 or float RGB)."""
+    _check(lib().rt_scatter_shards(device, C.c_void_p(d_shards_ptr), C.c_size_t(pitch_bytes), n_shards, width, height, tile_rows,
+                                   mode, C.c_void_p(d_frame_ptr), C.c_void_p(stream)))
+
+
+def scatter_shards_host(shards_ptr: int, pitch_bytes: int, n_shards: int, width: int, height: int, tile_rows: int,
+                        mode: int, frame_ptr: int) -> None:
+    """rt_scatter_shards_host: the same on host memory."""
+    _check(lib().rt_scatter_shards_host(C.c_void_p(shards_ptr), C.c_size_t(pitch_bytes), n_shards, width, height, tile_rows,
+                                        mode, C.c_void_p(frame_ptr)))
 
 
 def camera_sweep(n_frames: int = 64, pos=(-5.0, 5.0, 5.0), rot=(135.0, -45.0, 0.0), frame_ms: float = 16.0):
@@ -548,14 +566,27 @@ class Scene:
                                             tile_rows, tile_first, tile_stride,
                                             C.c_void_p(d_out_ptr), C.c_void_p(stream)))
 
+    def render_tiles(self, cam_pos, trans16, width: int, height: int, max_bounces: int, mode: int,
+                     tile_rows: int, tile_first: int, tile_stride: int, out=None) -> np.ndarray:
+        """rt_render_tiles: this shard's rows into host memory (rows, width, 3) float32, or (rows, width, 4) uint8 with OUT_RGBA8."""
+        cam, tr = _f32(cam_pos), _f32(trans16)
+        rows = shard_rows(height, tile_rows, tile_first, tile_stride)
+        if out is None:
+            out = np.empty((rows, width, 4), dtype=np.uint8) if mode & OUT_RGBA8 else np.empty((rows, width, 3), dtype=np.float32)
+        ptr = out.ctypes.data if isinstance(out, np.ndarray) else int(out)
+        _check(lib().rt_render_tiles(self._h, _p(cam), _p(tr), width, height, max_bounces, mode, tile_rows, tile_first, tile_stride,
+                                     C.c_void_p(ptr)))
+        return out
+
     def render_multi(self, devices: Iterable[int], cam_pos, trans16, width: int, height: int,
                      max_bounces: int = 1, mode: int = STRICT, tile_rows: int = 16) -> np.ndarray:
+        """rt_render_multi -> (height, width, 3) float32, or (height, width, 4) uint8 with OUT_RGBA8."""
         devs_l = [int(x) for x in devices]
         devs = (C.c_int * len(devs_l))(*devs_l)
         cam, tr = _f32(cam_pos), _f32(trans16)
-        out = np.empty((height, width, 3), dtype=np.float32)
+        out = np.empty((height, width, 4), dtype=np.uint8) if mode & OUT_RGBA8 else np.empty((height, width, 3), dtype=np.float32)
         _check(lib().rt_render_multi(self._h, devs, len(devs), _p(cam), _p(tr), width, height, max_bounces,
-                                     mode, tile_rows, _p(out)))
+                                     mode, tile_rows, C.cast(C.c_void_p(out.ctypes.data), _fp)))
         return out
 
     def cast_rays(self, rays7) -> np.ndarray:

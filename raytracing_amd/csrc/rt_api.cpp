@@ -593,6 +593,27 @@ int rt_render_tiles_device(rt_scene* s, int device, const float cam_pos[3], cons
 	return launch_render(sc, fp, d->accel, RT_RENDER_STRICT, false, (hipStream_t)hip_stream);
 }
 
+int rt_render_tiles(rt_scene* s, const float cam_pos[3], const float trans16[16], int width, int height, int max_bounces,
+                    int render_flags, int tile_rows, int tile_first, int tile_stride, float* out_compact) {
+	if (!s) { set_error("rt_render_tiles: NULL scene"); return RT_ERR_INVALID; }
+	if (!out_compact) { set_error("rt_render_tiles: NULL output"); return RT_ERR_INVALID; }
+	if (s->first_device < 0) { set_error("rt_render_tiles: scene is not committed to any device"); return RT_ERR_STATE; }
+	if (tile_rows <= 0 || tile_first < 0 || tile_stride <= 0 || height <= 0 || width <= 0) { set_error("rt_render_tiles: bad tile parameters"); return RT_ERR_INVALID; }
+	const int device = s->first_device;
+	DeviceGuard g(device);
+	if (!g.ok) return g.rc;
+	DeviceState* d = committed("rt_render_tiles", s, device);
+	if (!d) return RT_ERR_STATE;
+	const size_t bytes = (size_t)rt_shard_rows(height, tile_rows, tile_first, tile_stride) * (size_t)width * ((render_flags & RT_OUT_RGBA8) ? 4 : 3 * sizeof(float));
+	if (bytes == 0) return check_frame_args("rt_render_tiles", s, cam_pos, trans16, width, height, max_bounces);
+	int rc = ensure_frame(*d, bytes);
+	if (rc != RT_OK) return rc;
+	rc = rt_render_tiles_device(s, device, cam_pos, trans16, width, height, max_bounces, render_flags, tile_rows, tile_first, tile_stride, (float*)d->frame, nullptr);
+	if (rc != RT_OK) return rc;
+	RT_HIP(hipMemcpy(out_compact, d->frame, bytes, hipMemcpyDeviceToHost));
+	return RT_OK;
+}
+
 int rt_render_frames_device(rt_scene* s, int device, int n_frames, const float* cam_pos3, const float* trans16,
                             int width, int height, int max_bounces, int render_flags,
                             float* d_out_rgb, size_t frame_stride_floats, void* hip_stream) {
@@ -727,10 +748,9 @@ int rt_render_multi(rt_scene* s, const int* devices, int n_devices, const float 
 	int rc = check_frame_args("rt_render_multi", s, cam_pos, trans16, width, height, max_bounces);
 	if (rc != RT_OK) return rc;
 	if (!devices || n_devices <= 0 || !out_rgb || tile_rows <= 0) { set_error("rt_render_multi: bad argument"); return RT_ERR_INVALID; }
-	if ((rc = check_flags("rt_render_multi", render_flags)) != RT_OK) return rc;
-	for (int a = 0; a < n_devices; a++)
-		for (int b = a + 1; b < n_devices; b++)
-			if (devices[a] == devices[b]) { set_error("rt_render_multi: device %d listed twice", devices[a]); return RT_ERR_INVALID; }
+	if ((rc = check_flags("rt_render_multi", render_flags, true)) != RT_OK) return rc;
+	// (a device may be listed more than once: it then renders several shards, one after the other — a rehearsal of the N-GPU
+	// tile assignment on fewer GPUs)
 	// 1. commit where needed (keeps the acceleration choice of the first committed device)
 	int accel = RT_ACCEL_AUTO;
 	for (int k = 0; k < n_devices; k++) {
@@ -744,22 +764,32 @@ int rt_render_multi(rt_scene* s, const int* devices, int n_devices, const float 
 			if (rc != RT_OK) return rc;
 		}
 	}
-	// 2. every device renders its interleaved row tiles into a compact buffer (its scratch frame)
-	const size_t row_bytes = (size_t)width * 3 * sizeof(float);
+	// 2. every device renders its interleaved row tiles into a compact buffer: devices[0] straight into its piece of the
+	//    gather area on devices[0] (shard k at k * pitch, then the frame), the others into their scratch frames
+	const bool rgba8 = (render_flags & RT_OUT_RGBA8) != 0;
+	const size_t row_bytes = (size_t)width * (rgba8 ? 4 : 3 * sizeof(float));
 	const size_t frame_bytes = row_bytes * (size_t)height;
+	size_t pitch = (size_t)rt_shard_rows(height, tile_rows, 0, n_devices) * row_bytes;       // (shard 0 is the largest)
+	pitch = (pitch + 255) & ~(size_t)255;
+	const size_t frame_at = pitch * (size_t)n_devices;
 	const int root = devices[0];
 	std::vector<hipStream_t> streams((size_t)n_devices, nullptr);
+	std::vector<hipEvent_t> landed((size_t)n_devices, nullptr);
+	std::vector<void*> extra((size_t)n_devices, nullptr);          // shard buffers of a non-root device's second, third ... listing
 	auto cleanup = [&]() {
-		for (int k = 0; k < n_devices; k++)
-			if (streams[k]) { (void)hipSetDevice(devices[k]); (void)hipStreamDestroy(streams[k]); }
+		for (int k = 0; k < n_devices; k++) {
+			if (streams[k] || landed[k] || extra[k]) (void)hipSetDevice(devices[k]);
+			if (extra[k]) (void)hipFree(extra[k]);
+			if (landed[k]) (void)hipEventDestroy(landed[k]);
+			if (streams[k]) (void)hipStreamDestroy(streams[k]);
+		}
 	};
 	int prev = -1;
 	(void)hipGetDevice(&prev);
-	// the frame the shards are gathered into lives on devices[0]
 	if (hipSetDevice(root) != hipSuccess) { set_error("rt_render_multi: hipSetDevice(%d) failed", root); (void)hipGetLastError(); return RT_ERR_DEVICE; }
 	{
 		DeviceState& d0 = s->dev[root];
-		rc = ensure_buffer(d0.gather, d0.gather_bytes, frame_bytes);
+		rc = ensure_buffer(d0.gather, d0.gather_bytes, frame_at + frame_bytes);
 	}
 	for (int k = 1; k < n_devices && rc == RT_OK; k++) {
 		// let devices[k] write into devices[0]'s memory directly (xGMI); already enabled is fine
@@ -768,30 +798,51 @@ int rt_render_multi(rt_scene* s, const int* devices, int n_devices, const float 
 			(void)hipDeviceEnablePeerAccess(root, 0);        // (without it the peer copy below is staged through the host)
 		(void)hipGetLastError();
 	}
+	char* const area = (char*)s->dev[root].gather;
 	for (int k = 0; k < n_devices && rc == RT_OK; k++) {
 		DeviceState& d = s->dev[devices[k]];
 		const int rows = rt_shard_rows(height, tile_rows, k, n_devices);
 		if (hipSetDevice(devices[k]) != hipSuccess) { rc = RT_ERR_DEVICE; set_error("rt_render_multi: hipSetDevice(%d) failed", devices[k]); break; }
 		if (hipStreamCreateWithFlags(&streams[k], hipStreamNonBlocking) != hipSuccess) { rc = RT_ERR_DEVICE; set_error("rt_render_multi: stream creation failed"); break; }
-		if (rows == 0) continue;
-		rc = ensure_frame(d, (size_t)rows * row_bytes);
-		if (rc != RT_OK) break;
-		rc = rt_render_tiles_device(s, devices[k], cam_pos, trans16, width, height, max_bounces, render_flags,
-		                            tile_rows, k, n_devices, (float*)d.frame, streams[k]);
-		if (rc != RT_OK) break;
-		// 3. the exchange step: this shard's tiles go straight to their rows of the frame on devices[0],
-		//    queued behind the render on the same stream (7 concurrent xGMI transfers into GPU 0 on a full node)
-		char* const dst0 = (char*)s->dev[root].gather;
-		size_t src_row = 0;
-		for (long long t = k; t * tile_rows < height && rc == RT_OK; t += n_devices) {
-			long long r0 = t * tile_rows, r1 = r0 + tile_rows;
-			if (r1 > height) r1 = height;
-			const size_t bytes = (size_t)(r1 - r0) * row_bytes;
-			hipError_t e = devices[k] == root
-				? hipMemcpyAsync(dst0 + (size_t)r0 * row_bytes, (const char*)d.frame + src_row * row_bytes, bytes, hipMemcpyDeviceToDevice, streams[k])
-				: hipMemcpyPeerAsync(dst0 + (size_t)r0 * row_bytes, root, (const char*)d.frame + src_row * row_bytes, devices[k], bytes, streams[k]);
-			if (e != hipSuccess) rc = hip_fail(e, "rt_render_multi gather");
-			src_row += (size_t)(r1 - r0);
+		if (hipEventCreateWithFlags(&landed[k], hipEventDisableTiming) != hipSuccess) { rc = RT_ERR_DEVICE; set_error("rt_render_multi: event creation failed"); break; }
+		if (rows > 0) {
+			float* target = (float*)(area + (size_t)k * pitch);          // devices[0] renders where the shard belongs
+			if (devices[k] != root) {
+				bool first = true;
+				for (int a = 0; a < k; a++) first = first && devices[a] != devices[k];
+				if (first) {
+					rc = ensure_frame(d, (size_t)rows * row_bytes);
+					if (rc != RT_OK) break;
+					target = (float*)d.frame;
+				} else {
+					hipError_t e = hipMalloc(&extra[k], (size_t)rows * row_bytes);
+					if (e != hipSuccess) { rc = hip_fail(e, "rt_render_multi shard buffer"); break; }
+					target = (float*)extra[k];
+				}
+			}
+			rc = rt_render_tiles_device(s, devices[k], cam_pos, trans16, width, height, max_bounces, render_flags,
+			                            tile_rows, k, n_devices, target, streams[k]);
+			if (rc != RT_OK) break;
+			// 3. the exchange step: ONE peer copy per device, queued behind its render (7 concurrent xGMI transfers into GPU 0 on a full node)
+			if (devices[k] != root) {
+				hipError_t e = hipMemcpyPeerAsync(area + (size_t)k * pitch, root, target, devices[k], (size_t)rows * row_bytes, streams[k]);
+				if (e != hipSuccess) { rc = hip_fail(e, "rt_render_multi gather"); break; }
+			}
+		}
+		hipError_t e = hipEventRecord(landed[k], streams[k]);
+		if (e != hipSuccess) { rc = hip_fail(e, "rt_render_multi event"); break; }
+	}
+	// 4. devices[0] de-interleaves the shards into the frame (one kernel) and copies it to the caller once
+	if (rc == RT_OK) {
+		(void)hipSetDevice(root);
+		for (int k = 1; k < n_devices && rc == RT_OK; k++) {
+			hipError_t e = hipStreamWaitEvent(streams[0], landed[k], 0);
+			if (e != hipSuccess) rc = hip_fail(e, "rt_render_multi wait");
+		}
+		if (rc == RT_OK) rc = launch_scatter_shards(area, pitch, n_devices, row_bytes, height, tile_rows, area + frame_at, streams[0]);
+		if (rc == RT_OK) {
+			hipError_t e = hipMemcpyAsync(out_rgb, area + frame_at, frame_bytes, hipMemcpyDeviceToHost, streams[0]);
+			if (e != hipSuccess) rc = hip_fail(e, "rt_render_multi copy to host");
 		}
 	}
 	for (int k = 0; k < n_devices; k++) {
@@ -800,15 +851,46 @@ int rt_render_multi(rt_scene* s, const int* devices, int n_devices, const float 
 		hipError_t e = hipStreamSynchronize(streams[k]);
 		if (e != hipSuccess && rc == RT_OK) rc = hip_fail(e, "rt_render_multi sync");
 	}
-	// 4. one copy of the gathered frame from devices[0] to the caller
-	if (rc == RT_OK) {
-		(void)hipSetDevice(root);
-		hipError_t e = hipMemcpy(out_rgb, s->dev[root].gather, frame_bytes, hipMemcpyDeviceToHost);
-		if (e != hipSuccess) rc = hip_fail(e, "rt_render_multi copy to host");
-	}
 	cleanup();
 	if (prev >= 0) (void)hipSetDevice(prev);
 	return rc;
+}
+
+// The de-interleave on its own, for exchanges that run outside this library (torch.distributed / RCCL, MPI): SURVEY 8e.
+static int check_scatter(const char* fn, const void* shards, size_t pitch_bytes, int n_shards, int width, int height, int tile_rows, int render_flags, const void* frame, size_t* row_bytes) {
+	if (!shards || !frame || n_shards <= 0 || width <= 0 || height <= 0 || tile_rows <= 0) { set_error("%s: bad argument", fn); return RT_ERR_INVALID; }
+	int rc = check_flags(fn, render_flags, true);
+	if (rc != RT_OK) return rc;
+	*row_bytes = (size_t)width * ((render_flags & RT_OUT_RGBA8) ? 4 : 3 * sizeof(float));
+	if (pitch_bytes % 4 != 0 || pitch_bytes < (size_t)rt_shard_rows(height, tile_rows, 0, n_shards) * *row_bytes) {
+		set_error("%s: pitch %zu is smaller than the largest shard (%d rows of %zu bytes) or not a multiple of 4", fn, pitch_bytes, rt_shard_rows(height, tile_rows, 0, n_shards), *row_bytes);
+		return RT_ERR_INVALID;
+	}
+	return RT_OK;
+}
+
+int rt_scatter_shards(int device, const void* d_shards, size_t pitch_bytes, int n_shards, int width, int height, int tile_rows,
+                      int render_flags, void* d_frame, void* hip_stream) {
+	size_t row_bytes = 0;
+	int rc = check_scatter("rt_scatter_shards", d_shards, pitch_bytes, n_shards, width, height, tile_rows, render_flags, d_frame, &row_bytes);
+	if (rc != RT_OK) return rc;
+	DeviceGuard g(device);
+	if (!g.ok) return g.rc;
+	return launch_scatter_shards(d_shards, pitch_bytes, n_shards, row_bytes, height, tile_rows, d_frame, (hipStream_t)hip_stream);
+}
+
+int rt_scatter_shards_host(const void* shards, size_t pitch_bytes, int n_shards, int width, int height, int tile_rows,
+                           int render_flags, void* frame) {
+	size_t row_bytes = 0;
+	int rc = check_scatter("rt_scatter_shards_host", shards, pitch_bytes, n_shards, width, height, tile_rows, render_flags, frame, &row_bytes);
+	if (rc != RT_OK) return rc;
+	// tile t = rows [t * tile_rows, ...) is rank (t % n)'s (t / n)-th tile: whole tiles move in one memcpy each
+	for (long long t = 0; t * tile_rows < height; t++) {
+		const long long r0 = t * tile_rows, r1 = std::min<long long>(r0 + tile_rows, height);
+		const char* src = (const char*)shards + (size_t)(t % n_shards) * pitch_bytes + (size_t)(t / n_shards) * (size_t)tile_rows * row_bytes;
+		memcpy((char*)frame + (size_t)r0 * row_bytes, src, (size_t)(r1 - r0) * row_bytes);
+	}
+	return RT_OK;
 }
 
 // ---- the hand-off to the viewer, pipelined (Source.cpp:1270) -------------------------------------

@@ -259,6 +259,7 @@ DevScene dev_scene(const rt_scene* s, const DeviceState& d);
 bool use_packets(const DevScene& sc, const float trans16[16], int width, int height);   // the launcher's choice for an LBVH scene
 int launch_render(const DevScene& sc, const FrameParams& fp, int accel, int render_flags, bool count, hipStream_t stream);
 int launch_cast_rays(const DevScene& sc, int accel, int n, const float* d_rays7, float* d_out6, hipStream_t stream);
+int launch_scatter_shards(const void* shards, size_t pitch_bytes, int n, size_t row_bytes, int height, int tile_rows, void* frame, hipStream_t stream);   // rt_shards.hip
 int launch_hoist_masks(const DevScene& sc, const FrameParams& fp, hipStream_t stream);   // rt_vis.inl
 int launch_vis_raster(const DevScene& sc, const FrameParams& fp, const unsigned char* d_skip, bool count, hipStream_t stream);   // rt_vis.inl
 

@@ -105,6 +105,26 @@ def scatter_all_into_frame(full, recv, height: int, width: int, tile_rows: int, 
             fv[base + whole * e: base + whole * e + n] = rv[whole, g_full * e: g_full * e + n]
 
 
+def scatter_all_native(full, recv, height: int, width: int, tile_rows: int, world: int, channels: int, pitch: int, device: int = 0) -> None:
+    """:func:`scatter_all_into_frame` by the library (rt_scatter_shards: one kernel on the current stream for GPU tensors;
+    rt_scatter_shards_host: one memcpy per tile for host tensors and numpy arrays) — no tensor operations in the interpreter.
+    `channels` and `pitch` count elements: 3 float32 per pixel, or 1 32-bit element per OUT_RGBA8 pixel."""
+    from . import api
+    mode = api.STRICT | (api.OUT_RGBA8 if channels == 1 else 0)
+    if hasattr(full, "data_ptr"):
+        esize, fptr, rptr, on_gpu = full.element_size(), full.data_ptr(), recv.data_ptr(), bool(full.is_cuda)
+    else:
+        esize, fptr, rptr, on_gpu = full.itemsize, full.ctypes.data, recv.ctypes.data, False
+    if esize != 4:
+        raise ValueError("frames are held as 32-bit elements (float32 RGB or one packed RGBA8 pixel)")
+    if on_gpu:
+        import torch
+        api.scatter_shards(full.device.index if full.device.index is not None else device, rptr, pitch * 4, world, width, height,
+                           tile_rows, mode, fptr, torch.cuda.current_stream(full.device).cuda_stream)
+    else:
+        api.scatter_shards_host(rptr, pitch * 4, world, width, height, tile_rows, mode, fptr)
+
+
 class TileExchange:
     """Pipelined form of :func:`gather_frame` for a sequence of frames: `depth` shard buffers per
     rank, so that frame f+1 is rendered while frame f is still on its way to rank 0.
@@ -122,8 +142,8 @@ class TileExchange:
     The exchange of a frame is ONE non-blocking `gather` to rank 0 (RCCL runs it as grouped sends and
     receives: the 7 transfers into GPU 0 use their xGMI links concurrently): every rank's shard buffer is padded
     to the size of the largest shard so that the pieces are equal, and rank 0 de-interleaves all of them with
-    :func:`scatter_all_into_frame` — per frame one collective call and two or three copies on rank 0,
-    whatever the number of ranks.
+    :func:`scatter_all_native` — per frame one collective call and ONE kernel of the library on rank 0 (rt_scatter_shards),
+    whatever the number of ranks; :func:`scatter_all_into_frame` is the same thing in tensor operations, kept as the tests' check.
     """
 
     def __init__(self, dist, rank: int, world: int, height: int, width: int, tile_rows: int, alloc, depth: int = 2,
@@ -155,7 +175,7 @@ class TileExchange:
     def submit(self, f: int):
         k = f % self.depth
         if self.world == 1:
-            scatter_shard_into_frame(self._full[k], self._shards[k][: self.n], self.h, self.w, self.tile_rows, 0, 1, self.ch)
+            scatter_all_native(self._full[k], self._shards[k], self.h, self.w, self.tile_rows, 1, self.ch, self.pitch)
             return [(f, self._full[k])]
         pieces = None
         if self.rank == 0:
@@ -192,7 +212,7 @@ class TileExchange:
             if self._work[k] is not None:
                 self._work[k].wait()
                 self._work[k] = None
-            scatter_all_into_frame(self._full[k], self._recv[k], self.h, self.w, self.tile_rows, self.world, self.ch, self.pitch)
+            scatter_all_native(self._full[k], self._recv[k], self.h, self.w, self.tile_rows, self.world, self.ch, self.pitch)
             done.append((f, self._full[k]))
         return done
 

@@ -85,9 +85,8 @@ def test_glsl_through_the_tree_tiles_batches_rgba8_and_async(oracle):
         sc.render_wait(sc.render_async(desc.cam_pos, tr, W, H, desc.depth, hf, GLSL))
         assert np.array_equal(_bits(hf.array), _bits(want))
         hf.close()
-        # not a mode of the in-process multi-GPU call, and unknown bits are still errors
-        with pytest.raises(api.RtError):
-            sc.render_multi([0], desc.cam_pos, tr, W, H, desc.depth, GLSL)
+        # the in-process multi-GPU call takes the flag too (its shards are rt_render_tiles_device's); unknown bits are still errors
+        assert np.array_equal(_bits(sc.render_multi([0, 0], desc.cam_pos, tr, W, H, desc.depth, GLSL, tile_rows=8)), _bits(want))
         with pytest.raises(api.RtError):
             sc.render(desc.cam_pos, tr, W, H, desc.depth, 0x400)
 

@@ -181,6 +181,24 @@ def test_scatter_all_shapes_at_once():
         tfull = torch.zeros(h * w * ch, dtype=torch.int32)
         sharding.scatter_all_into_frame(tfull, torch.from_numpy(recv), h, w, tr, n, ch, pitch)
         assert np.array_equal(tfull.numpy().reshape(h, w * ch), want), (h, w, tr, n, ch)
+        # the library's own de-interleave (rt_scatter_shards_host: what TileExchange calls for host buffers)
+        for make in (lambda a: a, torch.from_numpy):
+            nfull = np.zeros(h * w * ch, np.int32)
+            sharding.scatter_all_native(make(nfull), make(recv), h, w, tr, n, ch, pitch)
+            assert np.array_equal(nfull.reshape(h, w * ch), want), (h, w, tr, n, ch)
+
+
+def test_scatter_host_rejects_bad_arguments():
+    from raytracing_amd import api
+    a = np.zeros(64, np.int32)
+    with pytest.raises(api.RtError):
+        api.scatter_shards_host(a.ctypes.data, 4, 2, 4, 8, 2, api.STRICT | api.OUT_RGBA8, a.ctypes.data)      # pitch below the largest shard
+    with pytest.raises(api.RtError):
+        api.scatter_shards_host(a.ctypes.data, 64, 0, 4, 8, 2, api.STRICT, a.ctypes.data)
+    with pytest.raises(api.RtError):
+        api.scatter_shards_host(0, 64, 2, 4, 8, 2, api.STRICT, a.ctypes.data)
+    with pytest.raises(api.RtError):
+        api.scatter_shards_host(a.ctypes.data, 64, 2, 4, 8, 2, 0x400, a.ctypes.data)
 
 
 def test_frames_round_robin():
