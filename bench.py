@@ -303,6 +303,8 @@ def device_info(torch, dev):
 # registers 2.5, the same with an SGPR operand 4.1 (the PMC mix cannot tell the two apart: low and high estimate); v_rcp/v_sqrt 8.2;
 # compares, selects, min/max, conversions, integer and lane ops 4.1
 CPI_ARITH_LOW, CPI_ARITH_HIGH, CPI_TRANS, CPI_OTHER = 2.5, 4.1, 8.2, 4.1
+XGMI_LINK_GBPS = 153.0        # per link and direction; 7 links per GPU, point to point (MI355X_MICROARCH.md)
+HBM_GBPS = 8000.0
 SIMDS = 1024
 CLOCK_GHZ = 2.4
 
@@ -547,21 +549,21 @@ def run_tile_mode(args, api, torch, dist, rank, world, dev, on_gpu, name):
         rgba8 = fmt == "rgba8"
         ch, dtype, mode = (1, torch.int32, api.STRICT | api.OUT_RGBA8) if rgba8 else (3, torch.float32, api.STRICT)
         ex = sharding.TileExchange(dist, rank, world, H, W, tile_rows, lambda n: torch.empty(n, dtype=dtype, device=where), depth=2, channels=ch)
-        stage = None if on_gpu else torch.empty(rows * W * ch, dtype=dtype, device="cuda")   # gloo rehearsal: shards go through host memory
+        # (gloo rehearsal: the shards go through host memory — rt_render_tiles renders and copies back inside the library)
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in frames]
 
         def run(fs, timed):
             done = []
             for i, f in enumerate(fs):
                 buf = ex.shard(i)
-                dst = buf if on_gpu else stage
                 if timed:
                     evs[i][0].record()
-                sc.render_tiles_device(dev, w.cams[f], w.trans[f], W, H, D, mode, tile_rows, rank, world, dst.data_ptr(), w.stream)
+                if on_gpu:
+                    sc.render_tiles_device(dev, w.cams[f], w.trans[f], W, H, D, mode, tile_rows, rank, world, buf.data_ptr(), w.stream)
+                else:
+                    sc.render_tiles(w.cams[f], w.trans[f], W, H, D, mode, tile_rows, rank, world, out=buf.data_ptr())
                 if timed:
                     evs[i][1].record()
-                if not on_gpu:
-                    buf.copy_(stage)
                 done += ex.submit(i)
             done += ex.drain()
             return done
@@ -647,9 +649,18 @@ def run_tile_mode(args, api, torch, dist, rank, world, dev, on_gpu, name):
             "exchange": {"format": fmt, "kernel_ms_rank0": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
                          "non_render_ms_per_frame": wall / args.steps * 1e3 - kernel_ms_max,
                          "shard_MB": rows * W * bytes_px[fmt] / 1e6,
+                         # the bound the links set: every other rank's shard crosses ITS OWN xGMI link into rank 0's GPU (7 links x
+                         # ~153 GB/s per GPU, MI355X_MICROARCH.md), concurrently — one shard over one link; and the render at its best
+                         "model_ms": (rows * W * bytes_px[fmt]) / XGMI_LINK_GBPS / 1e6 if world > 1 else 0.0,
+                         "scatter_model_ms": 2.0 * H * W * bytes_px[fmt] / HBM_GBPS / 1e6,
+                         "render_ms_ideal": single["ms_per_frame"] / world if single else None,
+                         "de_interleave": "rt_scatter_shards (one kernel of the library on rank 0 per frame)" if on_gpu
+                                          else "rt_scatter_shards_host (one memcpy per tile inside the library)",
                          "note": "roofline is rank 0's shard kernel: the frame's counted FLOPs x its share of the rows (%d of %d, interleaved "
                                  "tiles); non_render_ms_per_frame = wall per frame minus the slowest rank's kernel = exchange + "
-                                 "de-interleave not hidden behind rendering" % (rows, H)},
+                                 "de-interleave not hidden behind rendering; model_ms = shard bytes / 153 GB/s (one xGMI link per peer, "
+                                 "all peers at once); scatter_model_ms = frame bytes read + written at 8 TB/s; render_ms_ideal = the "
+                                 "single-GPU frame / ranks" % (rows, H)},
             "exchange_other_format": {"format": other, "frames": k2, "ms_per_frame": wall2 / k2 * 1e3,
                                       "value": float(sum(w.rays_of[f] for f in frames[:k2])) / wall2 / 1e6,
                                       "kernel_ms_max_over_ranks": kmax2, "shard_MB": rows * W * bytes_px[other] / 1e6},
@@ -690,6 +701,18 @@ def main():
     tile_mode = world > 1 and name.startswith("sweep8k")
     if tile_mode:
         out = run_tile_mode(args, api, torch, dist, rank, world, dev, on_gpu, name)
+        if not args.no_configs and name != "sweep8k_spheres":
+            # the heavier partition of the same frame size (102 412 triangles through the tree): it shards better than the room
+            steps, warm = args.steps, args.warmup
+            args.steps, args.warmup = min(8, steps), min(2, warm)
+            side = run_tile_mode(args, api, torch, dist, rank, world, dev, on_gpu, "sweep8k_spheres")
+            args.steps, args.warmup = steps, warm
+            if rank == 0:
+                out["configs"] = [{"workload": "sweep8k_spheres", "label": side["config"]["workload"], "n_gpus": world, "steps": side["steps"],
+                                   "value": side["value"], "unit": side["unit"], "ms_per_frame": side["ms_per_frame"], "scaling": "strong",
+                                   "build": side["config"]["build"], "traversal": side["config"]["traversal"],
+                                   "roofline_frac": side["roofline"]["frac"], "exchange": side["exchange"], "single_gpu": side["single_gpu"],
+                                   "gather_check": side["gather_check"]}]
     else:
         out = run_frames_mode(args, api, torch, dist, rank, world, dev, on_gpu, name)
     if rank == 0:
