@@ -388,18 +388,30 @@ def hand_off(api, torch, w):
     frame): a lone launch, rt_render into pageable memory, rt_render_async into two pinned buffers."""
     sc, W, H, D = w.scene, w.W, w.H, w.D
     n = 40
-    buf = torch.empty(H * W * 3, dtype=torch.float32, device="cuda")
+    bufs = [torch.empty(H * W * 3, dtype=torch.float32, device="cuda") for _ in range(2)]
+    s0 = torch.cuda.current_stream()
+    side = [torch.cuda.Stream(), torch.cuda.Stream()]
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for timed in (False, True):
-        if timed:
+    single = {}
+    # back-to-back single-frame launches: on ONE stream a frame cannot start before the last wavefront of the one before has ended;
+    # on two alternating streams (what rt_render_async does with its two slots) the ramp and tail of neighbours overlap
+    for label, streams, reps in (("one_stream", [s0, s0], 10), ("two_streams", side, 10)):
+        for timed in (False, True):
             torch.cuda.synchronize()
-            ev0.record()
-        for i in range(n):
-            sc.render_device(w.dev, w.cams[i % N_POSES], w.trans[i % N_POSES], W, H, D, api.STRICT, buf.data_ptr(), w.stream)
-        if timed:
-            ev1.record()
-    torch.cuda.synchronize()
-    single_us = ev0.elapsed_time(ev1) / n * 1e3
+            if timed:
+                ev0.record(s0)
+                for st in side:
+                    st.wait_stream(s0)
+            for i in range(n * reps):
+                sc.render_device(w.dev, w.cams[i % N_POSES], w.trans[i % N_POSES], W, H, D, api.STRICT, bufs[i & 1].data_ptr(), streams[i & 1].cuda_stream)
+            if timed:
+                for st in side:
+                    s0.wait_stream(st)
+                ev1.record(s0)
+        torch.cuda.synchronize()
+        single[label] = ev0.elapsed_time(ev1) / (n * reps) * 1e3
+    single_us = single["two_streams"]
+    del bufs
     sc.render(w.cams[0], w.trans[0], W, H, D)
     t0 = time.perf_counter()
     for i in range(n):
@@ -420,10 +432,11 @@ def hand_off(api, torch, w):
         for b in bufs:
             b.close()
     mb = H * W * 12 / 1e6
-    return {"single_frame_launch_us": single_us, "end_to_end_ms": sync_ms, "end_to_end_async_ms": async_ms[False],
+    return {"single_frame_launch_us": single_us, "single_frame_launch_one_stream_us": single["one_stream"], "end_to_end_ms": sync_ms, "end_to_end_async_ms": async_ms[False],
             "frame_MB": mb, "async_GBps": mb / async_ms[False],
             "end_to_end_async_rgba8_ms": async_ms[True], "frame_rgba8_MB": mb / 3,
-            "note": "one %dx%d frame per launch (HIP events, %d back-to-back launches); end_to_end_ms = rt_render incl. the D2H copy into "
+            "note": "one %dx%d frame per launch (HIP events, 10 x %d back-to-back launches, alternating between two streams as rt_render_async's two slots "
+                    "do; _one_stream_us: all on one stream); end_to_end_ms = rt_render incl. the D2H copy into "
                     "pageable memory; end_to_end_async_ms = rt_render_async into two pinned frames, frame f copying while f+1 renders "
                     "(wall per frame); end_to_end_async_rgba8_ms = the same with RT_OUT_RGBA8 frames (the 8-bit pixels the viewer displays)" % (W, H, n)}
 

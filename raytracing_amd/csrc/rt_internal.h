@@ -211,7 +211,7 @@ struct DeviceState {
 	// rt_render_async: two device frames, a render and a copy stream, per slot "rendered" / "copied" events
 	void* aframe[2] = { nullptr, nullptr };
 	size_t aframe_bytes[2] = { 0, 0 };
-	hipStream_t render_stream = nullptr, copy_stream = nullptr;
+	hipStream_t render_stream = nullptr, render_stream2 = nullptr, copy_stream = nullptr;   // (slot 0 renders on the first, slot 1 on the second: the ramp and tail of consecutive frames overlap)
 	hipEvent_t rendered[2] = { nullptr, nullptr }, copied[2] = { nullptr, nullptr };
 	long long ticket_of_slot[2] = { -1, -1 };
 };
@@ -231,8 +231,6 @@ struct rt_scene {
 	int build = RT_BUILD_PLOC;            // rt_scene_set_build (takes effect at the next LBVH commit)
 	int shadow_grid = 1;                  // rt_scene_set_shadow_grid (takes effect at the next LBVH commit)
 	int primary_raster = RT_PRIMARY_AUTO; // rt_scene_set_primary_raster
-	int uv_w = -1, uv_h = -1;             // frame size the division-free u, v were last checked for (rt_api.cpp fill_frame)
-	bool uv_fast = false;
 };
 
 namespace rt {

@@ -1604,7 +1604,12 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 #else
 	const bool bands = blocks <= 24000;
 #endif
-	if (accel == RT_ACCEL_LBVH && !count && n_frames >= 8 && bands) {
+#ifdef RT_EXPERIMENT
+	static const int band_min_frames = [] { const char* e = getenv("RT355_BAND_MIN_FRAMES"); return e ? atoi(e) : 8; }();
+#else
+	const int band_min_frames = 8;
+#endif
+	if (accel == RT_ACCEL_LBVH && !count && n_frames >= band_min_frames && bands) {
 		const long long band_blocks = (blocks + 7) / 8;
 		if (band_blocks * 8 * n_frames <= 0x7fffffffLL) {
 			fp.band_blocks = (unsigned int)band_blocks;
