@@ -1315,13 +1315,28 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 	}
 	const int tiles_x = (fp.width + RT_TILE_W - 1) / RT_TILE_W;
 	const int tiles_y = (fp.local_rows + RT_TILE_H - 1) / RT_TILE_H;
-	const unsigned int n_tiles = (unsigned int)tiles_x * (unsigned int)tiles_y;
+	// Brute force: a wave's run of tiles goes DOWN a column of tiles — wave w has column w % tiles_x of the band of tiles_per_wave
+	// tile rows w / tiles_x.  The tiles left and right of it are then rendered by the neighbouring waves at about the same time,
+	// and the 128-byte lines two of them share (a tile row is 96 bytes of RGB) are completed in the L2 before it writes them back;
+	// with runs ALONG a row the halves of such a line were stored a tile's time apart and went to memory twice (measured, room
+	// 7680x4320, WRITE_SIZE / frame bytes at 1 | 2 | 4 | 8 tiles per wave: 1.000 | 1.008 | 1.035 | 1.079, now 1.000 throughout;
+	// scripts/write_ratio.sh).  The tree kernels keep runs along the row (theirs are one tile long, two at 8K: 1.04 there): the
+	// column form costs the packet kernel seven spilled vector registers, whose scratch traffic more than doubled its writes.
 	const unsigned int wave = __builtin_amdgcn_readfirstlane(block_in_frame * (blockDim.x >> 6) + (threadIdx.x >> 6));
-	unsigned int tile = wave * (unsigned int)tiles_per_wave;          // (tiles_per_wave <= 1024 and wave < 2^21: no wrap)
-	unsigned int tile_end = tile + (unsigned int)tiles_per_wave;
-	if (tile_end > n_tiles) tile_end = n_tiles;
-	if (tile >= tile_end) return;
-	int ty = (int)(tile / (unsigned int)tiles_x), tx = (int)(tile - (unsigned int)ty * (unsigned int)tiles_x);
+	int tx, ty, left;                                                 // this wave's next tile, and how many it still has
+	if constexpr (ACCEL == 0 || ACCEL == 1) {
+		const unsigned int band_of_wave = wave / (unsigned int)tiles_x;
+		tx = (int)(wave - band_of_wave * (unsigned int)tiles_x);
+		ty = (int)(band_of_wave * (unsigned int)tiles_per_wave);      // (tiles_per_wave <= 1024 and wave < 2^21: no wrap)
+		left = min(tiles_per_wave, tiles_y - ty);
+	} else {
+		const unsigned int n_tiles = (unsigned int)tiles_x * (unsigned int)tiles_y;
+		const unsigned int tile = wave * (unsigned int)tiles_per_wave;
+		ty = (int)(tile / (unsigned int)tiles_x);
+		tx = (int)(tile - (unsigned int)ty * (unsigned int)tiles_x);
+		left = tile < n_tiles ? (int)min((unsigned int)tiles_per_wave, n_tiles - tile) : 0;
+	}
+	if (left <= 0) return;
 	const int lx = (int)(threadIdx.x & (RT_TILE_W - 1)), lyi = (int)((threadIdx.x & 63u) / RT_TILE_W);
 	const c4ptr lights = c4ptr_of(sc.lights);
 	WaveProf wp = {};
@@ -1340,10 +1355,11 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 			if (vis_list_n > RT_VIS_LIST_MAX) vis_list_n = -1;                  // too many triangles the pass could not project: this frame walks the tree
 		}
 	}
-	for (; tile < tile_end; tile++) {
+	for (; left > 0; left--) {
 		const int x = tx * RT_TILE_W + lx, ly = ty * RT_TILE_H + lyi;
 		const bool inside = (x < fp.width) && (ly < fp.local_rows);
-		if (++tx == tiles_x) { tx = 0; ty++; }
+		if constexpr (ACCEL == 0 || ACCEL == 1) ty++;
+		else if (++tx == tiles_x) { tx = 0; ty++; }
 		// ---- primary ray (Source.cpp:534-548)
 		vec3 d;
 		if constexpr (PLAIN) d = primary_dir_plain(x, ly, fp, frame);
@@ -1571,7 +1587,10 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 	// (tree kernels: one tile, except frames of 400k tiles and more — 102k triangles, measured 1 | 2 tiles: 3840x2160 214.6 | 222.7 us,
 	// 7680x4320 799 | 773)
 	if (fp.tiles_per_wave <= 0 && lockstep && accel == RT_ACCEL_LBVH && tiles >= 400000) tpw = 2;
-	const long long waves = (tiles + tpw - 1) / tpw;
+	// (the brute-force lockstep kernels run a wave's tiles down a column: whole columns of ceil(tile rows / tpw) bands; the others along rows)
+	const long long tiles_x = (fp.width + RT_TILE_W - 1) / RT_TILE_W, tiles_y = (fp.local_rows + RT_TILE_H - 1) / RT_TILE_H;
+	const bool column_runs = lockstep && accel != RT_ACCEL_LBVH;
+	const long long waves = column_runs ? tiles_x * ((tiles_y + tpw - 1) / tpw) : (tiles + tpw - 1) / tpw;
 #ifdef RT_EXPERIMENT
 	static const int env_block = [] { const char* e = getenv("RT355_BLOCK_THREADS"); int v = e ? atoi(e) : 0; return (v == 64 || v == 128 || v == 256) ? v : 0; }();
 	const int threads = env_block ? env_block : 256;
