@@ -170,6 +170,28 @@ def mirrors(w: int = 3840, h: int = 2160, depth: int = 16) -> SceneDesc:
     return sc.light((0, 8, 0), 4096)
 
 
+def mirror_checker(w: int = 800, h: int = 800, depth: int = 8, n: int = 16) -> SceneDesc:
+    """Config 3 with bounce depths that diverge INSIDE 8x8 tiles: the two facing mirrors of mirrors(), each
+    overlaid with an n x n checker of matte patches (every other cell, a hair in front of the glass).  A ray
+    ends on the first patch it meets, so neighbouring pixels stop after different numbers of bounces — the
+    patches' images shrink with every reflection (an image k bounces deep is 1/(2k+1) the size), down to a
+    few pixels.  2 n^2 + 16 triangles."""
+    sc = SceneDesc("mirror_checker", width=w, height=h, depth=depth, cam_pos=(0.5, -1.0, 0.25), cam_rot=(7.0, 3.0, 0.0))
+    _room(sc)
+    sc.quad((0, 0, 3), (0, 0, 0), (10, 10, 10), (200, 220, 255), 1)
+    sc.quad((0, 0, -3), (0, 0, 0), (10, 10, 10), (255, 220, 200), 1)
+    cell = 20.0 / n
+    for side, z in ((0, 3.0 - 0.01), (1, -3.0 + 0.01)):
+        for j in range(n):
+            for i in range(n):
+                if (i + j + side) % 2:
+                    continue
+                cx, cy = -10.0 + (i + 0.5) * cell, -10.0 + (j + 0.5) * cell
+                col = (230, 60 + (37 * i) % 160, 60 + (53 * j) % 160) if side == 0 else (60 + (41 * i) % 160, 230, 60 + (29 * j) % 160)
+                sc.quad((cx, cy, z), (0, 0, 0), (cell / 2, cell / 2, 1), col, 0)
+    return sc.light((0, 8, 0), 4096)
+
+
 def two_lights(w: int = 100, h: int = 100) -> SceneDesc:
     """Stock scene plus the second light the reference keeps commented out (Source.cpp:881)."""
     sc = stock(w, h)
@@ -260,6 +282,7 @@ BUILTIN = {
     "room": room,
     "mirrors": mirrors,
     "two_lights": two_lights,
+    "mirror_checker": mirror_checker,
 }
 
 

@@ -28,5 +28,10 @@ for seed, n, depth in [(1, 40, 8), (3, 120, 16), (7, 100, 8), (9, 24, 16)]:
     a = bench(desc, api.KERNEL_STATE_MACHINE)
     b = bench(desc, api.KERNEL_LOCKSTEP)
     print("soup seed %d, %d triangles, depth %d: state machine %.1f us/frame, lockstep %.1f" % (seed, n, depth, a, b))
-for d in (scenes.mirrors(1920, 1080, 16), scenes.room(800, 800)):
+# the facing mirrors under a checker of matte patches: neighbouring pixels stop after different numbers of bounces
+for n, size, depth in ((16, (800, 800), 8), (24, (1600, 900), 16), (32, (1920, 1080), 16)):
+    d = scenes.mirror_checker(size[0], size[1], depth, n)
+    print("mirror_checker n=%d %dx%d depth %d (%d triangles): state machine %.1f us/frame, lockstep %.1f" % (
+        n, size[0], size[1], depth, d.n_triangles, bench(d, api.KERNEL_STATE_MACHINE), bench(d, api.KERNEL_LOCKSTEP)))
+for d in (scenes.mirrors(1920, 1080, 16), scenes.mirrors(3840, 2160, 16), scenes.room(800, 800)):
     print(d.name, "state machine %.1f, lockstep %.1f" % (bench(d, api.KERNEL_STATE_MACHINE), bench(d, api.KERNEL_LOCKSTEP)))

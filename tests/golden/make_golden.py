@@ -74,6 +74,8 @@ def cases():
     nolight.ops = [op for op in nolight.ops if op[0] != "light"]
     nolight.name = "nolight"
     out.append(("nolight_32", nolight))
+    # bounce depths that diverge inside 8x8 tiles: the facing mirrors under a checker of matte patches
+    out.append(("mirror_checker_d8_128x72", scenes.mirror_checker(128, 72, 8, 10)))
     degen = scenes.stock(48, 48)
     degen.name = "degenerate"
     degen.tri((0, 2, 0), (0, 2, 0), (1, 2, 0), (9, 9, 9), 0)      # zero area -> NaN normal
@@ -257,11 +259,15 @@ def main():
             json.dump(index, f, indent=1, sort_keys=True)
             f.write("\n")
         return
-    index = {}
+    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]     # add cases without touching the others
+    index = json.load(open(os.path.join(HERE, "INDEX.json"))) if only else {}
     with tempfile.TemporaryDirectory() as tmp:
-        camera_case(tmp, index)
-        rto_cases(tmp, index)
+        if not only:
+            camera_case(tmp, index)
+            rto_cases(tmp, index)
         for name, sc in cases():
+            if only and name not in only:
+                continue
             text, tris, trans, frame, info = run_ref(sc, tmp)
             digest = hashlib.sha256(frame.tobytes()).digest()
             arrays = dict(scene=np.frombuffer(text.encode(), dtype=np.uint8), tris=tris, trans=trans,
@@ -279,6 +285,11 @@ def main():
             print("%-24s N=%-5d %4dx%-4d depth=%-2d  %7d B  %s" % (
                 name, info["triangles"], sc.width, sc.height, sc.depth, index[name]["bytes"], digest.hex()[:16]))
 
+        if only:
+            with open(os.path.join(HERE, "INDEX.json"), "w") as f:
+                json.dump(index, f, indent=1, sort_keys=True)
+                f.write("\n")
+            return
         sc, rays = ray_cases(rng)
         scene_path = os.path.join(tmp, "rays_scene.txt")
         with open(scene_path, "w") as f:

@@ -253,7 +253,8 @@ def test_tiles_per_wave_does_not_change_pixels():
 
 
 @pytest.mark.parametrize("name,size,depth", [("room", (200, 150), 1), ("room", (333, 77), 2), ("stock", (64, 64), 1),
-                                             ("mirrors", (192, 108), 16), ("mirrors", (96, 54), 0), ("two_lights", (80, 80), 1)])
+                                             ("mirrors", (192, 108), 16), ("mirrors", (96, 54), 0), ("two_lights", (80, 80), 1),
+                                             ("mirror_checker", (160, 120), 8), ("mirror_checker", (97, 61), 16)])   # bounce depths that differ inside a tile
 def test_both_kernel_forms_give_the_same_bits(oracle, name, size, depth):
     """rt_scene_set_kernel: the lockstep form (all lanes of a tile in step; what AUTO picks up to depth 2)
     and the state machine (lanes refilled as they finish; deep bounce loops) are the same arithmetic —
