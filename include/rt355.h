@@ -278,13 +278,16 @@ int rt_render_multi(rt_scene* s, const int* devices, int n_devices, const float 
  * Host pointers; synchronous. */
 int rt_cast_rays(rt_scene* s, int n_rays, const float* rays7, float* out6);
 
-/* rt_cast_rays for callers that cannot allocate device memory (code under HIP graph capture, tight
- * serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same
+/* rt_cast_rays for callers that cannot allocate device memory (harnesses that forbid hipMalloc, serving
+ * loops that must stay off the allocator, a process in which another thread is capturing a HIP graph — an
+ * allocation then would invalidate the capture).  It has no counterpart in the reference.  Same
  * arguments and results as rt_cast_rays, but the device copies of `rays7` and `out6` live in a
  * buffer that is part of the library image (one per GPU, RT_NOALLOC_MAX_RAYS rays = 832 KiB, held
  * until the process ends) instead of being hipMalloc'ed per call: the call allocates and frees
- * nothing.  n_rays > RT_NOALLOC_MAX_RAYS is RT_ERR_LIMIT.  All calls on one GPU share that buffer:
- * calls that overlap on one GPU race (serialise them); nothing in it needs to start at zero — a
+ * nothing.  n_rays > RT_NOALLOC_MAX_RAYS is RT_ERR_LIMIT.  Its two copies are blocking ones on the null
+ * stream, so the call itself is synchronous and cannot be recorded into a graph.  All calls on one GPU
+ * share that GPU's buffer: the library lets them in one at a time (a mutex per GPU), so calls from several
+ * host threads are safe and simply take turns; nothing in the buffer needs to start at zero — a
  * call overwrites the first n_rays slots of both halves and reads back only those. */
 #define RT_NOALLOC_MAX_RAYS 16384
 int rt_cast_rays_noalloc(rt_scene* s, int n_rays, const float* rays7, float* out6);

@@ -314,6 +314,7 @@ static __device__ __align__(256) float scratch[RT_SCRATCH_FLOATS];
 #define RT_MAX_DEVICES 64
 std::mutex g_scratch_mutex;
 float* g_scratch_ptr[RT_MAX_DEVICES];          // per HIP device ordinal; nullptr until looked up
+std::mutex g_scratch_in_use[RT_MAX_DEVICES];   // one call at a time per GPU: every call on a GPU stages through that GPU's one array
 
 // `device` must be current.
 int scratch_for_device(int device, float** out) {
@@ -1052,6 +1053,9 @@ int rt_cast_rays_noalloc(rt_scene* s, int n_rays, const float* rays7, float* out
 	if (rc != RT_OK) return rc;
 	float* const dr = base;                                              // n_rays x 7
 	float* const dout = base + (size_t)RT_NOALLOC_MAX_RAYS * 7;          // n_rays x 6
+	// (the copies are blocking and on the null stream: the call itself cannot be recorded into a HIP graph — it serves callers that
+	// must not ALLOCATE; calls from several host threads take turns on a GPU's array)
+	std::lock_guard<std::mutex> turn(g_scratch_in_use[device]);
 	RT_HIP(hipMemcpy(dr, rays7, (size_t)n_rays * 7 * sizeof(float), hipMemcpyHostToDevice));
 	rc = launch_cast_rays(dev_scene(s, *d), d->accel, n_rays, dr, dout, nullptr);
 	if (rc != RT_OK) return rc;

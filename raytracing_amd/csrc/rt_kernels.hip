@@ -1,18 +1,21 @@
 // rt_kernels.hip — the per-pixel render loop of the reference (getPixelData Source.cpp:530-628,
 // castRay Source.cpp:277-405, processLighting Source.cpp:460-494) as ONE fused gfx950 kernel.
 //
-// Shape of the kernel (MI355X-first, not the reference's call tree):
-//   * one lane == one pixel at a time; a wavefront (64 lanes) walks 8x8 pixel tiles;
-//   * brute force: every lane of the wave visits the SAME box or triangle per loop trip, so the
-//     scene's float4 SoA planes are read through the scalar cache (s_load, operands in SGPRs); the
-//     LBVH path walks a 4-wide quantised tree per lane (rt_lbvh_trav.inl);
-//   * the reference's recursion-by-call (primary castRay -> mirror loop castRays -> per-light
-//     shadow castRays) is flattened into a per-lane state machine with ONE closest-hit loop in the
-//     instruction stream: a lane holds "the ray it is waiting on" (primary, bounce or shadow) and
-//     all 64 lanes sit in that one loop together whatever their stage is;
-//   * lanes whose pixel is finished are refilled with fresh pixels from the wave's tile run using
-//     ballot + mbcnt prefix ranks ("ray regeneration"), so bounce-depth divergence (config 3:
-//     0..16 loop trips per pixel) compacts itself instead of idling lanes;
+// Two forms of the kernel, same arithmetic, same bits (MI355X-first, not the reference's call tree):
+//   * render_lockstep_kernel — what every launch uses unless rt_scene_set_kernel asks otherwise.  One lane == one pixel; a
+//     wavefront (64 lanes) takes one 8x8 pixel tile after the other and all its lanes stay in step: primary castRay -> (only if
+//     a lane hit a mirror) the bounce loop of Source.cpp:572-580 on those lanes -> per light one shadow castRay and the sum of
+//     Source.cpp:476-489 -> store.  Measured faster than, or equal to, the state machine on every scene tried, bounce depths
+//     that diverge inside a tile included (profiles/r03_config3_study.txt: 61 of 64 lanes active on the depth-16 mirror scene).
+//     Brute force (ACCEL 0/1): every lane visits the SAME box or triangle per loop trip, so the scene's float4 planes are read
+//     through the scalar cache (s_load, operands in SGPRs).  Tree scenes: ACCEL 3 walks the binary tree once per wavefront for a
+//     coherent tile of rays ("packets", cast_ray_packet: node records by scalar loads, the stack in one VGPR), ACCEL 2 per lane
+//     through the 4-wide quantised tree (rt_lbvh_trav.inl); shadow rays of both go through the light's direction grid
+//     (rt_lgrid_trav.inl) and the scene-spanning triangles kept out of the tree by direction masks (hoisted_by_mask);
+//   * render_kernel — the state machine (RT_KERNEL_STATE_MACHINE, and the RT_SHADE_GLSL checking mode): the reference's
+//     recursion-by-call flattened into per-lane stages with ONE closest-hit loop in the instruction stream; a lane holds "the ray
+//     it is waiting on" (primary, bounce or shadow), and lanes whose pixel is finished are refilled with fresh pixels from the
+//     wave's tile run (ballot + mbcnt prefix ranks).  It pays for that generality on every pass of its loop;
 //   * one launch renders up to RT_MAX_FRAMES frames (camera poses) of the same scene.
 //
 // Numerics: this TU is compiled with -ffp-contract=off and uses only unfused binary32 + - * / sqrt
@@ -20,6 +23,7 @@
 // the reference's CPU frames bit for bit.  Everything that skips work (boxes, limits, the
 // division-free prefilter) only ever skips; no filter decides a hit.
 #include "rt_internal.h"
+#include <type_traits>
 
 #include <cstdlib>
 #include <cmath>
@@ -1558,15 +1562,27 @@ static bool use_packets_cols(const DevScene& sc, const float col0[3], const floa
 }
 
 static int pick_tiles_per_wave(int accel, long long tiles) {
-	// 8x8 tiles per wavefront.  Measured: with two tiles a lane that finishes its pixel
-	// early (a miss, a matte hit next to a 16-bounce mirror path) takes the next pixel instead of
-	// idling — brute force gains 4 % on the room and stock scenes and the depth-16 mirror scene is at
-	// its best (373 us against 386 with one tile, 412 with 16); longer runs only add imbalance at the
-	// tail of the launch.  The LBVH kernel is best with one (its lanes are refilled less usefully:
-	// 93 against 101 us), and so are launches too small to fill the chip twice over.
+	// 8x8 tiles per wavefront for the STATE MACHINE (render_kernel: counting launches of brute-force scenes, RT_KERNEL_STATE_MACHINE,
+	// RT_SHADE_GLSL); the lockstep kernels' run lengths are chosen in launch_render.  Measured: with two tiles a
+	// lane that finishes its pixel early (a miss, a matte hit next to a 16-bounce mirror path) takes the next pixel instead of
+	// idling — brute force gains 4 % on the room and stock scenes and the depth-16 mirror scene is at its best (373 us against
+	// 386 with one tile, 412 with 16); longer runs only add imbalance at the tail of the launch.  The tree kernels are best with
+	// one, and so are launches too small to fill the chip twice over.
 	if (accel == RT_ACCEL_LBVH) return 1;
 	return tiles >= 4 * 8192 ? 2 : 1;          // 8192 wave slots on 256 CUs
 }
+
+// scene_from_kernel_args() re-reads DevScene from offset 0 of the kernel-argument segment: every kernel whose traces call it must
+// take the scene as its FIRST argument, by value.
+template <typename F> struct first_kernel_arg;
+template <typename A, typename... Rest> struct first_kernel_arg<void (*)(A, Rest...)> { typedef A type; };
+#define RT_SCENE_IS_FIRST_ARG(kernel) static_assert(std::is_same<first_kernel_arg<decltype(&kernel)>::type, DevScene>::value, #kernel ": DevScene must be the first kernel argument (scene_from_kernel_args)")
+RT_SCENE_IS_FIRST_ARG((render_kernel<0, false>));
+RT_SCENE_IS_FIRST_ARG((render_kernel<3, false>));
+RT_SCENE_IS_FIRST_ARG((render_lockstep_kernel<0, false, false>));
+RT_SCENE_IS_FIRST_ARG((render_lockstep_kernel<3, true, false>));
+RT_SCENE_IS_FIRST_ARG((cast_rays_kernel<0>));
+RT_SCENE_IS_FIRST_ARG((cast_rays_kernel<3>));
 
 int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int render_flags, bool count, hipStream_t stream) {
 	(void)render_flags;

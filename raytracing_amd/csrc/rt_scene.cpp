@@ -164,10 +164,12 @@ float scene_box(const std::vector<float>& tris, float lo[3], float hi[3]) {
 // Error budget, u = 2^-24, A = (|n.x|+|n.y|+|n.z|) * max_k (|e_k.x|+|e_k.y|+|e_k.z|), |w| the largest component of w:
 //   the reference's value against the real one: 6 roundings on the longest path (w_k, product, cross, product, two sums)
 //     of terms bounded by A * |w_k|, |w_k| <= |w| + |p_k - p1|                       <= 6 u A (|w| + E)
-//   s_k against the real one: M_k rounded from binary64 (u A |w|), c_1 rounded (u A E), c_2 dropped (u A E),
-//     three fma roundings of partial sums bounded by A (|w| + E)                      <= 5 u A (|w| + E)
-// with E = max(|p2 - p1|_1, |p3 - p1|_1).  11 u A (|w| + E) <= G |w|_1 + H for G = 16 u A, H = G E (both rounded up by
-// 2^-10) — no product may overflow or leave the normal range for this to hold, which the kernels make sure of by
+//   s_k against the real one: w = fl(I - p1) rounded per component (u A |w|), M_k rounded from binary64 (u A |w|), c_1
+//     rounded (u A E), c_2 dropped — edge_2 = fl(p1 - p3) is rounded per component, so M_2 . (p3 - p1) can reach 2 u A E —
+//     three fma roundings of partial sums bounded by A (|w| + E)                      <= 7 u A (|w| + E)
+// with E = max(|p2 - p1|_1, |p3 - p1|_1).  13 u A (|w| + E) <= G |w|_1 + H for G = 16 u A, H = G E (both rounded up by
+// 2^-10; a margin of 3 u A, not to be tightened on the strength of this count alone — tests/test_edge_filter_cpu.py pins the
+// filter against exact rational arithmetic on needle triangles, where the rounding of edge_2 is largest) — no product may overflow or leave the normal range for this to hold, which the kernels make sure of by
 // trusting the filter only for G |w|_1 + H < 1e20 (all partial results are then below 1e27) and raising the threshold to
 // 1e-20 where it is smaller (what underflow can add is 20 orders of magnitude below that).  A degenerate triangle
 // (n not finite) and one whose G is outside [1e-30, 1e30] get G = NaN: never trusted.
