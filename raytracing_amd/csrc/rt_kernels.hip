@@ -497,6 +497,9 @@ __device__ __forceinline__ Hit cast_ray_packet(const DevScene& sc, int oct, vec3
 	int stackv = 0;          // wave-uniform stack: entry k lives in lane k (a Karras tree over 63 key bits is at most 63 deep)
 	int sp = 0;
 	int node = 0;
+#ifdef RT_EXPERIMENT
+	if (!(sc.debug & 32))                                                     // (attribution: no tree walk, hoisted triangles only)
+#endif
 	for (;;) {
 		float4 q0, q1, q2, q3;
 		rec.quad((unsigned int)node * 4u, q0, q1, q2, q3);
@@ -706,7 +709,7 @@ __device__ __forceinline__ int global_row(int ly, const FrameParams& fp) {
 }
 
 // Source.cpp:534-545: u, v in double then rounded; dir = (trans * vec4(u, v, 0.5, 1)).xyz
-__device__ __forceinline__ vec3 primary_dir(int x, int y, const FrameParams& fp, int frame) {
+__device__ __forceinline__ vec3 primary_dir(int x, int y, const FrameParams& fp, int frame, const float* pose = nullptr) {
 	// (x - w/2.0) / (float)w in double, rounded to float.  For w, h < 2^22 the numerator is a
 	// half-integer below 2^22 and the denominator an integer: both exact in binary32, and rounding a
 	// binary64 quotient of binary32 operands to binary32 equals the correctly rounded binary32
@@ -731,7 +734,7 @@ __device__ __forceinline__ vec3 primary_dir(int x, int y, const FrameParams& fp,
 		v = (float)(((double)y - (double)hh / 2.0) / (double)(float)hh);
 		u = (float)(((double)x - (double)ww / 2.0) / (double)(float)ww);
 	}
-	const float* m = fp.pose[frame];       // 3..5: column 0, 6..8: column 1, 9..11: m2 * 0.5f + m3 * 1.0f (set_pose)
+	const float* m = pose ? pose : fp.pose[frame];       // 3..5: column 0, 6..8: column 1, 9..11: m2 * 0.5f + m3 * 1.0f (set_pose)
 	vec3 r;
 	r.x = (m[3] * u + m[6] * v) + m[9];
 	r.y = (m[4] * u + m[7] * v) + m[10];
@@ -740,13 +743,13 @@ __device__ __forceinline__ vec3 primary_dir(int x, int y, const FrameParams& fp,
 }
 
 // primary_dir for a launch whose u, v are division-free (FrameParams::uv_fast) — the branch-free body of the above
-__device__ __forceinline__ vec3 primary_dir_plain(int x, int y, const FrameParams& fp, int frame) {
+__device__ __forceinline__ vec3 primary_dir_plain(int x, int y, const FrameParams& fp, int frame, const float* pose = nullptr) {
 	const float hf = (float)fp.height, wf = (float)fp.width;
 	const float nv = (float)y - hf * 0.5f, nu = (float)x - wf * 0.5f;
 	const float qv = nv * fp.rcp_h, qu = nu * fp.rcp_w;
 	const float v = __builtin_fmaf(__builtin_fmaf(-qv, hf, nv), fp.rcp_h, qv);
 	const float u = __builtin_fmaf(__builtin_fmaf(-qu, wf, nu), fp.rcp_w, qu);
-	const float* m = fp.pose[frame];
+	const float* m = pose ? pose : fp.pose[frame];
 	vec3 r;
 	r.x = (m[3] * u + m[6] * v) + m[9];
 	r.y = (m[4] * u + m[7] * v) + m[10];
@@ -921,6 +924,35 @@ __device__ __forceinline__ DevScene scene_from_kernel_args(const DevScene& sc_ar
 #endif
 	return sc;
 }
+// The same for the scalar fields of FrameParams (everything behind the poses), which follows DevScene in the argument segment of
+// the render kernels (DevScene, FrameParams, int): what a tile needs of the frame at its END — the output pointer, strides, the
+// frame size — is read there instead of living in spilled SGPRs through the walks (each use of a spilled SGPR is a v_readlane).
+struct RenderKernelArgs { DevScene sc; FrameParams fp; int tiles_per_wave; };
+__device__ __forceinline__ FrameParams frame_from_kernel_args(const FrameParams& fp_arg) {
+	FrameParams fp = fp_arg;
+#if defined(__HIP_DEVICE_COMPILE__)
+	static_assert(sizeof(FrameParams) % 4 == 0 && offsetof(FrameParams, n_frames) % 4 == 0 && offsetof(RenderKernelArgs, fp) % 4 == 0, "copied word by word");
+	const __attribute__((address_space(4))) unsigned int* w = (const __attribute__((address_space(4))) unsigned int*)__builtin_amdgcn_kernarg_segment_ptr();
+	asm volatile("" : "+s"(w));
+	w += offsetof(RenderKernelArgs, fp) / 4;
+	unsigned int* dst = (unsigned int*)&fp;
+#pragma unroll
+	for (unsigned int k = offsetof(FrameParams, n_frames) / 4; k < sizeof(FrameParams) / 4; k++) dst[k] = w[k];
+#endif
+	return fp;
+}
+// ... and one frame's pose (12 floats at a wave-uniform offset of the same segment)
+__device__ __forceinline__ void pose_from_kernel_args(const FrameParams& fp_arg, int frame, float m[12]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	const __attribute__((address_space(4))) float* w = (const __attribute__((address_space(4))) float*)__builtin_amdgcn_kernarg_segment_ptr();
+	asm volatile("" : "+s"(w));
+	w += offsetof(RenderKernelArgs, fp) / 4 + (unsigned int)frame * 12u;
+#pragma unroll
+	for (int k = 0; k < 12; k++) m[k] = w[k];
+#else
+	for (int k = 0; k < 12; k++) m[k] = fp_arg.pose[frame][k];
+#endif
+}
 template <int ACCEL, int KIND>
 __device__ __forceinline__ Hit trace_brute(const DevScene& sc_arg, const float* lds_num0, vec3 o, vec3 d, int skip, bool live, float dist, WaveProf& wp) {
 	static_assert(ACCEL == 0 || ACCEL == 1, "brute force only");
@@ -1005,6 +1037,9 @@ __device__ __forceinline__ Hit trace_kind(const DevScene& sc, const float* lds_n
 template <int ACCEL, bool COUNT>
 __device__ __forceinline__ Hit trace_shadow(const DevScene& sc_arg, const float* lds_num0, int li, vec3 L, vec3 o, vec3 d, int skip, bool live, float dist,
                                             LaneCounters& lc, WaveProf& wp, const float4* lds_hoist = nullptr) {
+#ifdef RT_EXPERIMENT
+	if (sc_arg.debug & 64) { Hit h; h.t = 1e9f; h.idx = -1; h.p = make3(0.f, 0.f, 0.f); return h; }     // (attribution: no shadow work at all)
+#endif
 	if constexpr (ACCEL == 2 || ACCEL == 3) {
 		if (li < sc_arg.n_lgrid) {
 			const __attribute__((address_space(4))) LightGrid* G = (const __attribute__((address_space(4))) LightGrid*)(unsigned long long)(sc_arg.lgrid + li);
@@ -1342,7 +1377,6 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 	}
 	if (left <= 0) return;
 	const int lx = (int)(threadIdx.x & (RT_TILE_W - 1)), lyi = (int)((threadIdx.x & 63u) / RT_TILE_W);
-	const c4ptr lights = c4ptr_of(sc.lights);
 	WaveProf wp = {};
 #ifdef RT_PROFILE
 	wp.g = fp.counters;
@@ -1361,30 +1395,41 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 	}
 	for (; left > 0; left--) {
 		const int x = tx * RT_TILE_W + lx, ly = ty * RT_TILE_H + lyi;
-		const bool inside = (x < fp.width) && (ly < fp.local_rows);
+		// (tree kernels: what a tile needs of the frame is read from the kernel arguments tile by tile, and again at its end — held
+		// through the walks it sat in spilled SGPRs)
+		const FrameParams fp_top = (ACCEL == 2 || ACCEL == 3) ? frame_from_kernel_args(fp) : fp;
+		const bool inside = (x < fp_top.width) && (ly < fp_top.local_rows);
 		if constexpr (ACCEL == 0 || ACCEL == 1) ty++;
 		else if (++tx == tiles_x) { tx = 0; ty++; }
 		// ---- primary ray (Source.cpp:534-548)
-		vec3 d;
-		if constexpr (PLAIN) d = primary_dir_plain(x, ly, fp, frame);
-		else d = primary_dir(x, global_row(ly, fp), fp, frame);
+		vec3 d, cam_t = cam;
 		Hit h;
 		HoistCtx hc;
 		hc.lds = lds_hoist;
 		if constexpr (ACCEL == 2 || ACCEL == 3) {
-			if (fp.hoist_mask != nullptr) {                                  // which hoisted triangles this pixel's direction can meet (rt_vis.inl)
+			float m[12];
+			pose_from_kernel_args(fp, frame, m);
+			cam_t = make3(m[0], m[1], m[2]);
+			if constexpr (PLAIN) d = primary_dir_plain(x, ly, fp_top, frame, m);
+			else d = primary_dir(x, global_row(ly, fp_top), fp_top, frame, m);
+			if (fp_top.hoist_mask != nullptr) {                              // which hoisted triangles this pixel's direction can meet (rt_vis.inl)
 				hc.by_mask = true;
-				const int gy = PLAIN ? ly : global_row(ly, fp);
-				const int cu = min((int)((float)x * fp.hoist_cell_x), RT_HOIST_CELLS - 1), cv = min((int)((float)gy * fp.hoist_cell_y), RT_HOIST_CELLS - 1);
-				hc.hm = inside ? fp.hoist_mask[(frame * RT_HOIST_CELLS + cv) * RT_HOIST_CELLS + cu] : 0u;
+				const int gy = PLAIN ? ly : global_row(ly, fp_top);
+				const int cu = min((int)((float)x * fp_top.hoist_cell_x), RT_HOIST_CELLS - 1), cv = min((int)((float)gy * fp_top.hoist_cell_y), RT_HOIST_CELLS - 1);
+				hc.hm = inside ? fp_top.hoist_mask[(frame * RT_HOIST_CELLS + cv) * RT_HOIST_CELLS + cu] : 0u;
 			}
+		} else {
+			if constexpr (PLAIN) d = primary_dir_plain(x, ly, fp, frame);
+			else d = primary_dir(x, global_row(ly, fp), fp, frame);
 		}
-		if (vis_list_n >= 0) h = trace_primary_vis<ACCEL == 3 ? 3 : 2, COUNT>(sc, fp, frame, vis_list_n, (long long)ly * fp.width + x, cam, d, inside, lc, wp, hc);
-		else h = trace_kind<ACCEL, RAY_PRIMARY, COUNT>(sc, s_num0, cam, d, -1, inside, 0.f, lc, wp, hc);
+		if (vis_list_n >= 0) h = trace_primary_vis<ACCEL == 3 ? 3 : 2, COUNT>(sc, fp, frame, vis_list_n, (long long)ly * fp_top.width + x, cam_t, d, inside, lc, wp, hc);
+		else h = trace_kind<ACCEL, RAY_PRIMARY, COUNT>(sc, s_num0, cam_t, d, -1, inside, 0.f, lc, wp, hc);
 		const bool hit = inside && h.idx >= 0;
 		if constexpr (COUNT) { ctr[CTR_PRIMARY] += inside; ctr[CTR_PXHIT] += hit; }
 		float4 A = make_float4(0.f, 0.f, 0.f, 0.f);                          // colour, shininess of the triangle to be lit
-		if (hit) A = sc.planes[PL_COL * sc.stride + h.idx];
+		// (tree kernels: from here on the scene and the frame are re-read from the kernel arguments where they are used)
+		const DevScene sc_hit = (ACCEL == 2 || ACCEL == 3) ? scene_from_kernel_args(sc) : sc;
+		if (hit) A = sc_hit.planes[PL_COL * sc_hit.stride + h.idx];
 		bool bouncing = hit && A.w > 0.5f;                                   // Source.cpp:570
 #ifdef RT_EXPERIMENT
 		if (sc.debug & 8) bouncing = false;
@@ -1398,9 +1443,10 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 		if (__builtin_amdgcn_ballot_w64(bouncing) != 0ull) {
 			vec3 bo = h.p, bd = d;
 			int bskip = h.idx, bounces = 0;
+			const int max_bounces = (ACCEL == 2 || ACCEL == 3) ? frame_from_kernel_args(fp).max_bounces : fp.max_bounces;
 			{
 				float4 N4 = make_float4(0.f, 0.f, 0.f, 0.f);
-				if (bouncing) N4 = sc.planes[PL_N * sc.stride + h.idx];
+				if (bouncing) N4 = sc_hit.planes[PL_N * sc_hit.stride + h.idx];
 				bd = normalize(reflect(d, face_normal(d, xyz(N4))));         // Source.cpp:561, 572
 			}
 			while (__builtin_amdgcn_ballot_w64(bouncing) != 0ull) {
@@ -1408,8 +1454,8 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 				const Hit g = trace_kind<ACCEL, RAY_BOUNCE, COUNT>(sc, s_num0, bo, bd, bskip, bouncing, 0.f, lc, wp);   // Source.cpp:573, 578
 				const bool ghit = bouncing && g.idx >= 0;
 				float4 GA = make_float4(0.f, 0.f, 0.f, 0.f);
-				if (ghit) GA = sc.planes[PL_COL * sc.stride + g.idx];
-				const bool cont = ghit && bounces < fp.max_bounces && GA.w > 0.5f;   // Source.cpp:575
+				if (ghit) GA = sc_hit.planes[PL_COL * sc_hit.stride + g.idx];
+				const bool cont = ghit && bounces < max_bounces && GA.w > 0.5f;      // Source.cpp:575
 				if (ghit && !cont) {                                         // Source.cpp:582-586
 					hp = g.p; hidx = g.idx; A = GA;
 					dim = (float)(bounces * 1);
@@ -1417,7 +1463,7 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 				}                                                            // (a miss stays unlit: Source.cpp:590)
 				if (__builtin_amdgcn_ballot_w64(cont) != 0ull) {
 					float4 N4 = make_float4(0.f, 0.f, 0.f, 0.f);
-					if (cont) N4 = sc.planes[PL_N * sc.stride + g.idx];
+					if (cont) N4 = sc_hit.planes[PL_N * sc_hit.stride + g.idx];
 					if (cont) {                                              // Source.cpp:576-579
 						bd = normalize(reflect(bd, face_normal(bd, xyz(N4))));
 						bo = g.p;
@@ -1432,7 +1478,9 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 		vec3 color = make3(0.f, 0.f, 0.f);                                   // Source.cpp:462
 		bool lit_any = false;
 		if (__builtin_amdgcn_ballot_w64(shade) != 0ull) {
-			for (int li = 0; li < sc.n_lights; li++) {
+			const DevScene sc_lit = (ACCEL == 2 || ACCEL == 3) ? scene_from_kernel_args(sc) : sc;
+			const c4ptr lights = c4ptr_of(sc_lit.lights);
+			for (int li = 0; li < sc_lit.n_lights; li++) {
 				const float4 L = lights[li];
 				const vec3 ray = make3(L.x - hp.x, L.y - hp.y, L.z - hp.z);  // Source.cpp:470
 				const float s = sqrtf(dot(ray, ray));                        // magnitude(ray), Source.cpp:26-28
@@ -1456,7 +1504,12 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 			if (c.x > 1.0f) c.x = 1.0f;                                      // Source.cpp:602-610
 			if (c.y > 1.0f) c.y = 1.0f;
 			if (c.z > 1.0f) c.z = 1.0f;
-			store_pixel(fp, frame, (long long)ly * fp.width + x, c);        // (local rows)
+			if constexpr (ACCEL == 2 || ACCEL == 3) {
+				const FrameParams fp_end = frame_from_kernel_args(fp);
+				store_pixel(fp_end, frame, (long long)ly * fp_end.width + x, c);    // (local rows)
+			} else {
+				store_pixel(fp, frame, (long long)ly * fp.width + x, c);
+			}
 		}
 		if constexpr (COUNT) ctr[CTR_PXLIT] += lit_any;
 	}
