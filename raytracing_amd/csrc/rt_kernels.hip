@@ -1395,9 +1395,10 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 	}
 	for (; left > 0; left--) {
 		const int x = tx * RT_TILE_W + lx, ly = ty * RT_TILE_H + lyi;
-		// (tree kernels: what a tile needs of the frame is read from the kernel arguments tile by tile, and again at its end — held
-		// through the walks it sat in spilled SGPRs)
-		const FrameParams fp_top = (ACCEL == 2 || ACCEL == 3) ? frame_from_kernel_args(fp) : fp;
+		// (what a tile needs of the frame, the pose and the scene is read from the kernel arguments tile by tile where it is used, and
+		// again at the tile's end: held through the walks it sat in spilled SGPRs — packet kernel 39 -> 18 of them, 102k triangles
+		// 3840x2160 155 -> 147 us/frame; brute force +-0 on the room at 800x800, -1 % on the 4K mirrors and the 8K room)
+		const FrameParams fp_top = frame_from_kernel_args(fp);
 		const bool inside = (x < fp_top.width) && (ly < fp_top.local_rows);
 		if constexpr (ACCEL == 0 || ACCEL == 1) ty++;
 		else if (++tx == tiles_x) { tx = 0; ty++; }
@@ -1406,29 +1407,25 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 		Hit h;
 		HoistCtx hc;
 		hc.lds = lds_hoist;
-		if constexpr (ACCEL == 2 || ACCEL == 3) {
+		{
 			float m[12];
 			pose_from_kernel_args(fp, frame, m);
 			cam_t = make3(m[0], m[1], m[2]);
 			if constexpr (PLAIN) d = primary_dir_plain(x, ly, fp_top, frame, m);
 			else d = primary_dir(x, global_row(ly, fp_top), fp_top, frame, m);
-			if (fp_top.hoist_mask != nullptr) {                              // which hoisted triangles this pixel's direction can meet (rt_vis.inl)
+			if ((ACCEL == 2 || ACCEL == 3) && fp_top.hoist_mask != nullptr) {   // which hoisted triangles this pixel's direction can meet (rt_vis.inl)
 				hc.by_mask = true;
 				const int gy = PLAIN ? ly : global_row(ly, fp_top);
 				const int cu = min((int)((float)x * fp_top.hoist_cell_x), RT_HOIST_CELLS - 1), cv = min((int)((float)gy * fp_top.hoist_cell_y), RT_HOIST_CELLS - 1);
 				hc.hm = inside ? fp_top.hoist_mask[(frame * RT_HOIST_CELLS + cv) * RT_HOIST_CELLS + cu] : 0u;
 			}
-		} else {
-			if constexpr (PLAIN) d = primary_dir_plain(x, ly, fp, frame);
-			else d = primary_dir(x, global_row(ly, fp), fp, frame);
 		}
 		if (vis_list_n >= 0) h = trace_primary_vis<ACCEL == 3 ? 3 : 2, COUNT>(sc, fp, frame, vis_list_n, (long long)ly * fp_top.width + x, cam_t, d, inside, lc, wp, hc);
 		else h = trace_kind<ACCEL, RAY_PRIMARY, COUNT>(sc, s_num0, cam_t, d, -1, inside, 0.f, lc, wp, hc);
 		const bool hit = inside && h.idx >= 0;
 		if constexpr (COUNT) { ctr[CTR_PRIMARY] += inside; ctr[CTR_PXHIT] += hit; }
 		float4 A = make_float4(0.f, 0.f, 0.f, 0.f);                          // colour, shininess of the triangle to be lit
-		// (tree kernels: from here on the scene and the frame are re-read from the kernel arguments where they are used)
-		const DevScene sc_hit = (ACCEL == 2 || ACCEL == 3) ? scene_from_kernel_args(sc) : sc;
+		const DevScene sc_hit = scene_from_kernel_args(sc);
 		if (hit) A = sc_hit.planes[PL_COL * sc_hit.stride + h.idx];
 		bool bouncing = hit && A.w > 0.5f;                                   // Source.cpp:570
 #ifdef RT_EXPERIMENT
@@ -1443,7 +1440,7 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 		if (__builtin_amdgcn_ballot_w64(bouncing) != 0ull) {
 			vec3 bo = h.p, bd = d;
 			int bskip = h.idx, bounces = 0;
-			const int max_bounces = (ACCEL == 2 || ACCEL == 3) ? frame_from_kernel_args(fp).max_bounces : fp.max_bounces;
+			const int max_bounces = frame_from_kernel_args(fp).max_bounces;
 			{
 				float4 N4 = make_float4(0.f, 0.f, 0.f, 0.f);
 				if (bouncing) N4 = sc_hit.planes[PL_N * sc_hit.stride + h.idx];
@@ -1478,7 +1475,7 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 		vec3 color = make3(0.f, 0.f, 0.f);                                   // Source.cpp:462
 		bool lit_any = false;
 		if (__builtin_amdgcn_ballot_w64(shade) != 0ull) {
-			const DevScene sc_lit = (ACCEL == 2 || ACCEL == 3) ? scene_from_kernel_args(sc) : sc;
+			const DevScene sc_lit = scene_from_kernel_args(sc);
 			const c4ptr lights = c4ptr_of(sc_lit.lights);
 			for (int li = 0; li < sc_lit.n_lights; li++) {
 				const float4 L = lights[li];
@@ -1504,12 +1501,8 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 			if (c.x > 1.0f) c.x = 1.0f;                                      // Source.cpp:602-610
 			if (c.y > 1.0f) c.y = 1.0f;
 			if (c.z > 1.0f) c.z = 1.0f;
-			if constexpr (ACCEL == 2 || ACCEL == 3) {
-				const FrameParams fp_end = frame_from_kernel_args(fp);
-				store_pixel(fp_end, frame, (long long)ly * fp_end.width + x, c);    // (local rows)
-			} else {
-				store_pixel(fp, frame, (long long)ly * fp.width + x, c);
-			}
+			const FrameParams fp_end = frame_from_kernel_args(fp);
+			store_pixel(fp_end, frame, (long long)ly * fp_end.width + x, c);        // (local rows)
 		}
 		if constexpr (COUNT) ctr[CTR_PXLIT] += lit_any;
 	}
