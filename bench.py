@@ -327,9 +327,13 @@ def issue_use_of(workload, kernel_ms, fpl):
     arith, trans = e["valu_fp32_arith"] * k, e["valu_trans"] * k
     other = e["valu"] * k - arith - trans
     slots = SIMDS * kernel_ms * 1e-3 * CLOCK_GHZ * 1e9
-    low = (arith * CPI_ARITH_LOW + trans * CPI_TRANS + other * CPI_OTHER) / slots
-    high = (arith * CPI_ARITH_HIGH + trans * CPI_TRANS + other * CPI_OTHER) / slots
-    return {"low": low, "high": high, "valu_per_wave": e["valu"] / e["waves"], "salu_per_wave": e["salu"] / e["waves"],
+    # low: every non-transcendental instruction at the fastest rate measured (2.5: register-only arithmetic, moves, logic); high: FP32
+    # arithmetic with an SGPR operand and everything else at 4.1 — capped at 1: the kernel cannot fill more slots than there are, so
+    # a raw value above 1 says the mix is cheaper than the high prices (cycles_per_valu_if_issue_bound is the price at which it
+    # would be exactly 1)
+    low = ((arith + other) * CPI_ARITH_LOW + trans * CPI_TRANS) / slots
+    high_raw = (arith * CPI_ARITH_HIGH + trans * CPI_TRANS + other * CPI_OTHER) / slots
+    return {"low": min(1.0, low), "high": min(1.0, high_raw), "high_uncapped": high_raw, "valu_per_wave": e["valu"] / e["waves"], "salu_per_wave": e["salu"] / e["waves"],
             "cycles_per_valu_if_issue_bound": slots / (e["valu"] * k),
             "waves_resident_per_simd": e["wave_cycles_x4"] * 4.0 / (e["gui_active_all_xcds"] / 8.0 * SIMDS) if e.get("gui_active_all_xcds") else None,
             "profile_round": e.get("round"), "kernel": e.get("kernel")}
