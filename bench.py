@@ -214,8 +214,18 @@ class Workload:
             # what REALLY built the tree (a clustered build that cannot finish falls back to Karras'), and the build time of a
             # second commit: the first one in a process also loads the build kernels' code objects
             self.build_ms_first = self.scene.build_ms(dev)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
             self.scene.commit(dev, api.ACCEL_LBVH)
+            torch.cuda.synchronize()
+            self.commit_wall_ms = (time.perf_counter() - t0) * 1e3     # the whole rt_scene_commit: upload, tree, records, shadow grids
             self.build_ms = self.scene.build_ms(dev)
+            try:
+                g = [self.scene.shadow_grid(dev, k) for k in range(min(4, self.scene.n_lights))]
+            except api.RtError:
+                g = []
+            self.grid_ms = sum(x["build_ms"] for x in g[:1]) if g else 0.0     # (build_ms is the time of all the commit's grids together)
+            self.grids = [{k: x[k] for k in ("cells_per_edge", "entries", "always")} for x in g]
             self.build = {v: k for k, v in kinds.items()}[self.scene.build_kind(dev)]
         self.cams, self.trans = api.camera_sweep(N_POSES, desc.cam_pos, desc.cam_rot)     # (64,3), (64,16): rt_camera_path
         self.rays_of, self.flops_of = {}, {}
@@ -380,6 +390,9 @@ def side_config(api, torch, name, dev, args, launches=6, build=None):
             out["build_where"] = "host threads (topology) + GPU (boxes, records)" if w.build == "sah" else "GPU"
             out["build_ms"] = w.build_ms
             out["build_ms_first_commit"] = w.build_ms_first
+            out["shadow_grid_build_ms"] = w.grid_ms
+            out["shadow_grids"] = w.grids
+            out["commit_wall_ms"] = w.commit_wall_ms
             out["bvh_depth"] = list(w.scene.bvh_depth(dev))
         return out
     finally:

@@ -31,6 +31,7 @@
 // Entries are (distance from the light to B, triangle), sorted per cell by that distance: an accepted hit with
 // t in (0, dist] lies within dist of the light, so entries beyond dist * (1 + 1e-5) + 1e-6 * S end the list.
 #include "rt_internal.h"
+#include <chrono>
 
 #include <algorithm>
 #include <cmath>
@@ -232,6 +233,16 @@ void hoisted_masks(const rt_scene* s, const DeviceState& d, const float L[3], fl
 					const double u0 = -1.0 + 2.0 * cu / HC - m, u1 = -1.0 + 2.0 * (cu + 1) / HC + m;
 					const double v0 = -1.0 + 2.0 * cv / HC - m, v1 = -1.0 + 2.0 * (cv + 1) / HC + m;
 					const double pl[5][3] = { { 0, 0, 1 }, { 1, 0, -u0 }, { -1, 0, u1 }, { 0, 1, -v0 }, { 0, -1, v1 } };
+					// (most cells end here: all three corners outside one plane — clipping would leave nothing — or inside all five)
+					bool out = false, in = true;
+					for (int c = 0; c < 5 && !out; c++) {
+						double fv[3];
+						for (int k = 0; k < 3; k++) fv[k] = pl[c][0] * T[k][0] + pl[c][1] * T[k][1] + pl[c][2] * T[k][2];
+						out = fv[0] < 0.0 && fv[1] < 0.0 && fv[2] < 0.0;
+						in = in && fv[0] >= 0.0 && fv[1] >= 0.0 && fv[2] >= 0.0;
+					}
+					if (out) continue;
+					if (in) { mask[((size_t)f * HC + cv) * HC + cu] |= 1u << j; continue; }
 					double P[10][3], Q[10][3];
 					int n = 3;
 					for (int k = 0; k < 3; k++) for (int e = 0; e < 3; e++) P[k][e] = T[k][e];
@@ -312,6 +323,19 @@ int lgrid_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 		return RT_OK;
 	};
 
+#ifdef RT_EXPERIMENT
+	const bool times = std::getenv("RT355_LGRID_TIMES") != nullptr;
+	auto t_last = std::chrono::steady_clock::now();
+	auto lap = [&](const char* what) {
+		if (!times) return;
+		(void)hipStreamSynchronize(stream);
+		const auto now = std::chrono::steady_clock::now();
+		fprintf(stderr, "lgrid %-22s %8.1f us\n", what, std::chrono::duration<double, std::micro>(now - t_last).count());
+		t_last = now;
+	};
+#else
+	auto lap = [](const char*) {};
+#endif
 	std::vector<unsigned char> h_skip((size_t)n, 0);
 	for (int i : d.hoisted) h_skip[(size_t)i] = 1;
 	LG_TRY(dev_alloc(&skip, (size_t)n));
@@ -325,6 +349,7 @@ int lgrid_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 	const float4* planes = (const float4*)d.planes;
 	const unsigned int blocks_n = (unsigned int)((n + 255) / 256);
 	const size_t entry_budget = (size_t)n * 48 + (1u << 20);
+	lap("set-up, allocations");
 
 	for (int li = 0; li < ng; li++) {
 		const float* Lp = s->lights.data() + (size_t)li * 4;
@@ -338,9 +363,11 @@ int lgrid_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 		g.S = 4.0f * big;
 		g.pad = d.pad;
 		// resolution: cells of RT_LGRID_CELL mean triangle sizes as seen from the light
+		// (a sample of at most ~4096 triangles, evenly spread over the list: the resolution only has to be about right)
 		double sum = 0.0;
 		long long cnt = 0;
-		for (int i = 0; i < n; i++) {
+		const int sample_step = n > 4096 ? n / 4096 : 1;
+		for (int i = 0; i < n; i += sample_step) {
 			if (h_skip[(size_t)i]) continue;
 			const float* v = s->tris.data() + (size_t)i * RT_TRI_FLOATS + 6;
 			double e2 = 0.0, d2 = 0.0;
@@ -353,6 +380,7 @@ int lgrid_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 			if (d2 > 0.0 && e2 <= 0.25 * d2) { sum += sqrt(e2 / d2); cnt++; }
 		}
 		if (cnt == 0) continue;
+		lap("mean angular size");
 		float cell = RT_LGRID_CELL;
 #ifdef RT_EXPERIMENT
 		if (const char* e = std::getenv("RT355_LGRID_CELL")) cell = (float)atof(e);
@@ -390,6 +418,7 @@ int lgrid_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 			LG_HIP(hipMemcpyAsync(&total, tri_start + n, sizeof total, hipMemcpyDeviceToHost, stream));
 			LG_HIP(hipMemcpyAsync(h_over, over, sizeof h_over, hipMemcpyDeviceToHost, stream));
 			LG_HIP(hipStreamSynchronize(stream));
+			lap("count + scans");
 			if (h_over[RT_LGRID_OVER_MAX] > RT_LGRID_OVER_MAX || (size_t)total > entry_budget) {
 				d.lgrid_buffers.pop_back();
 				(void)hipFree(cell_start);
@@ -408,6 +437,7 @@ int lgrid_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 				LG_TRY(dev_alloc(&keys_sorted, (size_t)total));
 				LG_TRY(dev_alloc(&vals, (size_t)total));
 				LG_TRY(dev_alloc(&vals_sorted, (size_t)total));
+				lap("entry allocations");
 				hipLaunchKernelGGL(k_lg_fill, dim3(blocks_n), dim3(256), 0, stream, planes, d.stride, n, (const unsigned char*)skip, g, (const unsigned int*)tri_start, keys, vals);
 				LG_HIP(hipGetLastError());
 				unsigned int cell_bits = 1;
@@ -418,6 +448,7 @@ int lgrid_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 				hipLaunchKernelGGL(k_lg_pack, dim3((total + 255) / 256), dim3(256), 0, stream, (const u64*)keys_sorted, (const int*)vals_sorted, total, entries);
 				LG_HIP(hipGetLastError());
 			}
+			lap("fill + sort + pack");
 			LightGrid& t = table[(size_t)li];
 			t.cell_start = cell_start;
 			t.entries = entries;
@@ -436,6 +467,7 @@ int lgrid_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 				LG_HIP(hipMemcpy(dm, hm.data(), hm.size() * sizeof(unsigned int), hipMemcpyHostToDevice));
 				t.hmask = dm;
 			}
+			lap("hoisted masks");
 			d.lgrid_info[(size_t)li * 3] = R;
 			d.lgrid_info[(size_t)li * 3 + 1] = (long long)total;
 			d.lgrid_info[(size_t)li * 3 + 2] = t.n_over;

@@ -1,0 +1,12 @@
+import sys, os
+sys.path.insert(0, os.getcwd())
+from raytracing_amd import api, scenes
+desc = scenes.spheres(20, 4, 800, 800)
+with api.Scene.from_desc(desc) as sc:
+    for b, n in ((api.BUILD_PLOC, "ploc"), (api.BUILD_FAST, "fast")):
+        sc.set_build(b)
+        sc.commit(0, api.ACCEL_LBVH); sc.commit(0, api.ACCEL_LBVH)
+        print(n, "build_ms", sc.build_ms(0), "grid", sc.shadow_grid(0, 0), "depth", sc.bvh_depth(0), "hoisted", len(sc.hoisted(0)) if hasattr(sc, "hoisted") else None)
+    sc.set_shadow_grid(False)
+    sc.commit(0, api.ACCEL_LBVH); sc.commit(0, api.ACCEL_LBVH)
+    print("fast, no grid: build_ms", sc.build_ms(0))
