@@ -6,6 +6,7 @@
 // returns RT_ERR_DEVICE.
 #include "rt_internal.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -459,7 +460,21 @@ int rt_scene_commit(rt_scene* s, int device, int accel_flags) {
 	DeviceGuard g(device);
 	if (!g.ok) return g.rc;
 	DeviceState& d = s->dev[device];
+#ifdef RT_EXPERIMENT
+	const bool times = getenv("RT355_LGRID_TIMES") != nullptr;
+	auto t_last = std::chrono::steady_clock::now();
+	auto lap = [&](const char* what) {
+		if (!times) return;
+		(void)hipDeviceSynchronize();
+		const auto now = std::chrono::steady_clock::now();
+		fprintf(stderr, "commit %-22s %8.1f us\n", what, std::chrono::duration<double, std::micro>(now - t_last).count());
+		t_last = now;
+	};
+#else
+	auto lap = [](const char*) {};
+#endif
 	if (d.device >= 0) free_device_state(d);
+	lap("free previous state");
 	d.device = device;
 	const int n = (int)(s->tris.size() / RT_TRI_FLOATS);
 	const int nl = (int)(s->lights.size() / 4);
@@ -485,6 +500,7 @@ int rt_scene_commit(rt_scene* s, int device, int accel_flags) {
 		d.oct_clusters = L.oct_clusters; d.oct_groups = L.oct_groups;
 		d.oct_cluster_pitch = L.oct_cluster_pitch; d.oct_group_pitch = L.oct_group_pitch;
 	} catch (...) { set_error("rt_scene_commit: out of host memory"); return RT_ERR_NOMEM; }
+	lap("scene box, planes (host)");
 	// (the render kernels address the scene as a 64-bit base + 32-bit byte offset, rt_kernels.hip c4ptr)
 	if (planes.size() * sizeof(float) >= 0xffffffffull) { set_error("rt_scene_commit: %d triangles need a scene buffer of 4 GiB or more", n); return RT_ERR_LIMIT; }
 	RT_HIP(hipMalloc(&d.planes, planes.size() * sizeof(float)));
@@ -492,6 +508,7 @@ int rt_scene_commit(rt_scene* s, int device, int accel_flags) {
 	RT_HIP(hipMalloc(&d.lights, (size_t)(nl > 0 ? nl : 1) * 4 * sizeof(float)));
 	if (nl > 0) RT_HIP(hipMemcpy(d.lights, s->lights.data(), (size_t)nl * 4 * sizeof(float), hipMemcpyHostToDevice));
 	RT_HIP(hipMalloc(&d.counters, 32 * sizeof(unsigned long long)));
+	lap("upload");
 	d.build_ms = 0.f;
 	{   // scene diagonal over the mean triangle box diagonal (rt_kernels.hip launch_render: packet or per-lane traversal)
 		double sum = 0.0;
@@ -514,8 +531,10 @@ int rt_scene_commit(rt_scene* s, int device, int accel_flags) {
 		// tri_box_padded): the slab arithmetic stays inside that for origins up to 30 scene scales away
 		const float g = pad * 3e4f;
 		if (d.far_guard > g) d.far_guard = g;
+		lap("mean triangle size");
 		int rc = lbvh_build(s, d, nullptr);
 		if (rc != RT_OK) return rc;
+		lap("lbvh_build");
 		{   // which triangles the tree does not hold (the visibility pass leaves them to the render kernel)
 			std::vector<unsigned char> skip((size_t)(n > 0 ? n : 1), 0);
 			for (int i : d.hoisted) skip[(size_t)i] = 1;
@@ -524,6 +543,7 @@ int rt_scene_commit(rt_scene* s, int device, int accel_flags) {
 		}
 		rc = lgrid_build(s, d, nullptr);
 		if (rc != RT_OK) return rc;
+		lap("tri_skip + lgrid_build");
 	}
 	{   // set-up for rt_cast_rays_noalloc: this device's address of the library's staging array
 		float* unused = nullptr;
