@@ -342,6 +342,20 @@ __global__ void __launch_bounds__(256) k_packet(const float4* __restrict__ nodes
 	}
 }
 
+// 9. depth of a tree on the device (what the traversal stacks have to hold), level by level from the root: a launch of k_level
+//    gives every inner child of the nodes at `level` the level + 1 and notes that there was one.  `words` are the nodes as 16
+//    ints each, the `width` child references start at word `first`; a reference r with 0 <= r < n_nodes is an inner node,
+//    anything else a leaf or an empty slot.  (Walking up parent pointers instead does not work for the 4-wide collapse: every
+//    binary node has a 4-wide record, reachable or not, and several of them may name the same child.)
+__global__ void __launch_bounds__(256) k_level(const int* __restrict__ words, int n_nodes, int first, int width, int level, int* __restrict__ depth, int* __restrict__ deepest) {
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_nodes || depth[i] != level) return;
+	for (int c = 0; c < width; c++) {
+		const int r = words[(size_t)i * 16 + first + c];
+		if (r >= 0 && r < n_nodes) { depth[r] = level + 1; *deepest = level + 1; }      // (every writer of a launch stores the same value)
+	}
+}
+
 // 8. hoisted triangles (DevScene::hoist): their keys get the top bit, so they sort behind every
 //    triangle of the tree; their records are copied out in index order, followed by their padded
 //    boxes ordered near/far for each octant.  Two neighbours of the list whose boxes coincide (the two
@@ -657,29 +671,6 @@ void pick_hoisted(const std::vector<float>& tris, const float bb_lo[3], const fl
 	if ((long long)out.size() * 4 > n || n - (int)out.size() < 2) out.clear();
 }
 
-// Depth of a tree given as `width` child references per node at `refs` (node 0 is the root; a
-// reference >= 0 and < n_nodes is an inner node, anything else a leaf or an empty slot): the number
-// of inner-node levels on the longest path.  Host side, at commit, from a copy of the references.
-int tree_depth(const std::vector<int>& refs, int width, int n_nodes) {
-	if (n_nodes <= 0) return 0;
-	std::vector<std::pair<int, int>> todo;
-	todo.emplace_back(0, 1);
-	int depth = 0;
-	size_t visited = 0;
-	while (!todo.empty()) {
-		const std::pair<int, int> cur = todo.back();
-		todo.pop_back();
-		if (++visited > (size_t)n_nodes) return -1;              // not a tree
-		if (cur.second > depth) depth = cur.second;
-		for (int c = 0; c < width; c++) {
-			const int r = refs[(size_t)cur.first * width + c];
-			if (r >= 0 && r < n_nodes) todo.emplace_back(r, cur.second + 1);
-		}
-	}
-	return depth;
-}
-
-
 template <typename T>
 int dev_alloc(T** p, size_t count) {
 	hipError_t e = hipMalloc((void**)p, count * sizeof(T));
@@ -916,19 +907,41 @@ int lbvh_build(rt_scene* s, DeviceState& d, hipStream_t stream) {
 				return RT_ERR_DEVICE;
 			}
 		}
-		// Depths of the binary tree and of its 4-wide collapse, from host copies of the child references
-		// (16 B of every 64-byte node): what the traversal stacks have to hold (rt_lbvh_trav.inl header).
-		try {
-			// (whole arrays in one copy each: a strided hipMemcpy2D of 16 bytes per node takes a second per 100k nodes)
-			std::vector<int> all((size_t)(nt - 1) * 16), refs((size_t)(nt - 1) * 4);
-			LB_HIP(hipMemcpy(all.data(), nodes, (size_t)(nt - 1) * 64, hipMemcpyDeviceToHost));
-			for (size_t i = 0; i < (size_t)(nt - 1); i++) { refs[i * 2] = all[i * 16 + 12]; refs[i * 2 + 1] = all[i * 16 + 13]; }   // q3 = (left, right, 0, 0)
-			depth2 = tree_depth(refs, 2, nt - 1);
-			LB_HIP(hipMemcpy(all.data(), nodes4, (size_t)(nt - 1) * 64, hipMemcpyDeviceToHost));
-			for (size_t i = 0; i < (size_t)(nt - 1); i++)
-				for (int c = 0; c < 4; c++) { const int r = all[i * 16 + 4 + c]; refs[i * 4 + c] = r == RT_BVH4_EMPTY ? -1 : r; }       // w1 = the 4 child references
-			depth4 = tree_depth(refs, 4, nt - 1);
-		} catch (...) { set_error("LBVH: out of host memory measuring the tree"); rc = RT_ERR_NOMEM; }
+		// Depths of the binary tree and of its 4-wide collapse (what the traversal stacks have to hold: rt_lbvh_trav.inl header),
+		// measured on the device — reading both trees back for a host walk cost 2 ms of a commit's 12 at 100k triangles
+		{
+			int* dscratch = nullptr;                                   // levels (nt - 1), then the deepest level reached
+			LB_TRY(dev_alloc(&dscratch, (size_t)(nt - 1) + 1));
+			int h_depth[2] = { 0, 0 };
+			const unsigned int nb = (unsigned int)((nt - 1 + 255) / 256);
+			const int one = 1;
+			hipError_t de = hipSuccess;
+			for (int which = 0; which < 2 && de == hipSuccess; which++) {
+				// binary node: q3 = (left, right, 0, 0) at words 12, 13; 4-wide node: w1 = the 4 child references at words 4..7
+				const int* words = which == 0 ? (const int*)nodes : (const int*)nodes4;
+				const int first = which == 0 ? 12 : 4, width = which == 0 ? 2 : 4;
+				de = hipMemsetAsync(dscratch, 0, ((size_t)(nt - 1) + 1) * sizeof(int), stream);
+				if (de == hipSuccess) de = hipMemcpyAsync(dscratch, &one, sizeof one, hipMemcpyHostToDevice, stream);               // the root is level 1
+				if (de == hipSuccess) de = hipMemcpyAsync(dscratch + (nt - 1), &one, sizeof one, hipMemcpyHostToDevice, stream);
+				int level = 1, deepest = 1;
+				while (de == hipSuccess) {
+					const int batch = which == 0 ? 32 : 16;              // levels per read-back
+					for (int k = 0; k < batch; k++)
+						hipLaunchKernelGGL(k_level, dim3(nb), dim3(256), 0, stream, words, nt - 1, first, width, level + k, dscratch, dscratch + (nt - 1));
+					level += batch;
+					de = hipGetLastError();
+					if (de == hipSuccess) de = hipMemcpyAsync(&deepest, dscratch + (nt - 1), sizeof deepest, hipMemcpyDeviceToHost, stream);
+					if (de == hipSuccess) de = hipStreamSynchronize(stream);
+					if (deepest < level) break;                           // the last level of the batch had no inner children
+					if (level > 4096) { deepest = -1; break; }            // not a tree
+				}
+				h_depth[which] = deepest;
+			}
+			(void)hipFree(dscratch);
+			if (de != hipSuccess) { rc = hip_fail(de, "tree depth"); }
+			depth2 = h_depth[0];
+			depth4 = h_depth[1];
+		}
 		LB_TRY(rc);
 		if (ploc && depth2 > 63 && depth4 >= 1) { built = RT_BUILD_FAST; continue; }    // an agglomerated chain deeper than the packet stack: Karras' tree is at most 63 deep
 		break;

@@ -6,6 +6,7 @@
 // they must be the bits the reference's own constructors produce.  sinf/cosf come from the host
 // libm exactly as they do for the reference (glm::rotate -> std::cos / std::sin).
 #include "rt_internal.h"
+#include <thread>
 
 #include <cerrno>
 #include <cstdio>
@@ -225,7 +226,10 @@ PlaneLayout flatten_planes(const std::vector<float>& tris, int stride, float pad
 	const float inf = __builtin_huge_valf();
 	out.assign((size_t)PL_COUNT * stride * 4, 0.0f);
 	auto plane = [&](int k, int i) { return out.data() + ((size_t)k * stride + i) * 4; };
-	for (int i = 0; i < n; i++) {
+	// (per triangle and independent: large scenes are laid out by up to 8 host threads — 3.7 ms of a 12 ms commit at 100k triangles
+	// on one)
+	auto lay_out = [&](int i0, int i1) {
+	for (int i = i0; i < i1; i++) {
 		const float* t = tris.data() + (size_t)i * RT_TRI_FLOATS;
 		const float* nrm = t + 3; const float* p1 = t + 6; const float* p2 = t + 9; const float* p3 = t + 12;
 		const float* e0 = t + 15; const float* e1 = t + 18; const float* e2 = t + 21; const float* col = t + 24;
@@ -239,6 +243,21 @@ PlaneLayout flatten_planes(const std::vector<float>& tris, int stride, float pad
 		q = plane(PL_E2, i); q[0] = e2[0]; q[1] = e2[1]; q[2] = e2[2];
 		q = plane(PL_COL, i); q[0] = col[0]; q[1] = col[1]; q[2] = col[2]; q[3] = t[27];
 		edge_filter_planes(t, plane(PL_M0, i), plane(PL_M1, i), plane(PL_M2, i));
+	}
+	};
+	{
+		unsigned int hw = std::thread::hardware_concurrency();
+		const int workers = n < 16384 ? 1 : (int)(hw < 1 ? 1 : (hw > 8 ? 8 : hw));
+		if (workers <= 1) lay_out(0, n);
+		else {
+			std::vector<std::thread> pool;
+			const int chunk = (n + workers - 1) / workers;
+			for (int w = 0; w < workers; w++) {
+				const int i0 = w * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
+				if (i0 < i1) pool.emplace_back(lay_out, i0, i1);
+			}
+			for (std::thread& th : pool) th.join();
+		}
 	}
 	// padded boxes of groups of RT_GROUP consecutive triangles
 	for (int g = 0; g < stride; g++) {      // every slot past the last group is an empty box
