@@ -362,8 +362,10 @@ int         rt_scene_shadow_grid(const rt_scene* s, int device, int light, int* 
 #define RT_TRAVERSAL_PER_LANE 1   /* every lane walks the 4-wide tree with its own stack */
 #define RT_TRAVERSAL_PACKET   2   /* one walk of the binary tree per wavefront and direction octant */
 int         rt_scene_set_traversal(rt_scene* s, int mode);
-/* Which traversal a frame of this size and pose gets on `device`: RT_TRAVERSAL_PER_LANE or
- * RT_TRAVERSAL_PACKET for an LBVH commit, 0 for a brute-force commit. */
+/* Which traversal a frame of this size and pose gets on `device` in a launch long enough to run at steady state
+ * (RT_TRAVERSAL_AUTO walks launches of fewer than 90 000 tiles in all — a lone 800x800 frame — per lane whatever
+ * this says: their wavefronts all start cold): RT_TRAVERSAL_PER_LANE or RT_TRAVERSAL_PACKET for an LBVH commit,
+ * 0 for a brute-force commit. */
 int         rt_scene_traversal(const rt_scene* s, int device, const float trans16[16], int width, int height);
 const char* rt_last_error(void);
 const char* rt_version(void);

@@ -1671,7 +1671,16 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 	// 18.4 | 10.9, 500 (7.4) 20.4 | 15.5, 600 (6.1) 21.0 | 18.7, 800 (4.6) 26.4 | 29.0, 1000 (3.7) 34.3 | 41.6, 1200 (3.1) 44.4 | 55.9,
 	// 1600 (2.3) 67.9 | 90.5, 2400 (1.5) 127.5 | 183.5, 3840x2160 (1.3) 172.1 | 244.7: packets below a footprint of 5.5.
 	DevScene sc_sel = sc;
-	if (accel == RT_ACCEL_LBVH && !use_packets_cols(sc, fp.pose[0] + 3, fp.pose[0] + 6, fp.width, fp.height)) sc_sel.skip_count = 0;
+	if (accel == RT_ACCEL_LBVH) {
+		bool packets = use_packets_cols(sc, fp.pose[0] + 3, fp.pose[0] + 6, fp.width, fp.height);
+		// A SHORT launch walks per lane even where packets win at steady state: its wavefronts all start with cold caches, and the
+		// packet walk's chains of dependent scalar loads then cost far more than the per-lane walk's vector loads (the scalar cache
+		// serves few misses at a time).  Measured, 102k triangles, us per launch packets | per lane: one 800x800 frame 338 | 151, two
+		// 282 | 149, four 305 | 193, eight 366 | 274 (16 and more: packets); one 1600x1600 frame 252 | 185, two 253 | 241, four 371 | 399.
+		// (Counting launches keep the steady-state choice: they count for the batched launches that are timed.)
+		if (packets && !count && sc.traversal == RT_TRAVERSAL_AUTO && sc.per_lane_ok && tiles * n_frames < 90000) packets = false;
+		if (!packets) sc_sel.skip_count = 0;
+	}
 	dim3 grid((unsigned)(blocks * n_frames)), block((unsigned)threads);
 	// XCD-aware workgroup order for multi-frame LBVH launches (rt_internal.h FrameParams::band_blocks).
 	// Measured on the 100k-triangle scene, 32 frames per launch, us/frame without | with: 800x800 76 | 72
