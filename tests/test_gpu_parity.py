@@ -228,6 +228,32 @@ def test_async_hand_off_equals_render():
             b.close()
 
 
+def test_async_hand_off_of_a_tree_scene_on_two_render_streams(oracle):
+    """rt_render_async renders its two slots on streams of their own; on a tree scene every stream also carries its own
+    direction masks for the hoisted wall triangles.  Frames of different poses in flight together, each the oracle's."""
+    desc = scenes.spheres(4, 2, 192, 144, depth=2)
+    cams, trs = api.camera_sweep(12, desc.cam_pos, desc.cam_rot, frame_ms=90.0)
+    with api.Scene.from_desc(desc) as sc:
+        sc.commit(0, api.ACCEL_LBVH)
+        assert len(sc.hoisted(0)) > 0
+        want = [sc.render(cams[i], trs[i], 192, 144, desc.depth) for i in range(12)]
+        tris, lights = oracle.build_scene(desc)
+        for i in (0, 5, 11):
+            assert np.array_equal(_bits(want[i]), _bits(oracle.render(tris, lights, cams[i], trs[i], 192, 144, desc.depth))), i
+        bufs = [api.HostFrame(192, 144), api.HostFrame(192, 144)]
+        tickets = [None, None]
+        for rounds in range(3):
+            for i in range(12):
+                tickets[i & 1] = sc.render_async(cams[i], trs[i], 192, 144, desc.depth, bufs[i & 1])
+                if i > 0:
+                    sc.render_wait(tickets[(i - 1) & 1])
+                    assert np.array_equal(_bits(bufs[(i - 1) & 1].array), _bits(want[i - 1])), (rounds, i - 1)
+            sc.render_wait(tickets[11 & 1])
+            assert np.array_equal(_bits(bufs[1].array), _bits(want[11]))
+        for b in bufs:
+            b.close()
+
+
 def test_render_multi_single_device():
     desc = scenes.stock(120, 90)
     with api.Scene.from_desc(desc) as sc:
