@@ -7,10 +7,10 @@ per-pixel render loop at 800x800 on 1..8 MI355X (BASELINE.json `metric`).
 
 One GPU (the default): the workload is BASELINE config 2 — the README-style room (26 triangles, two
 mirror walls, blue occluder, one light), 800x800, reference depth 1.  A *step* is ONE LAUNCH of the
-render loop over a batch of 32 consecutive frames of the deterministic camera path of config 5
+render loop over a batch of consecutive frames (64 at 800x800: the whole path) of the deterministic camera path of config 5
 (rt_render_frames_device, include/rt355.h; the poses come from the reference's own controller,
 api.camera_sweep -> rt_camera_path), into framebuffers that stay resident in HBM; the scene is
-committed before the timed region starts.  K steps = 32*K frames.  `value` = rays of all frames /
+committed before the timed region starts.  K steps = 64*K frames at 800x800.  `value` = rays of all frames /
 wall time.  The line also carries, measured outside the timed region of the headline:
   configs       the other BASELINE configs on this GPU (stock 800x800, facing mirrors 3840x2160 depth
                 16, 102 412 triangles through the LBVH at 800x800 and 3840x2160 with the build time,
@@ -54,10 +54,10 @@ N_POSES = 64
 # name -> (scene builder, acceleration, label, frames per launch)
 WORKLOADS = {
     "room800": (lambda s: s.room(800, 800), "brute",
-                "README room scene (26 triangles, 2 mirror walls, occluder, 1 light) 800x800 depth 1", 32),
-    "stock800": (lambda s: s.stock(800, 800), "brute", "unmodified v1 scene (24 triangles, 1 light) 800x800 depth 1", 32),
+                "README room scene (26 triangles, 2 mirror walls, occluder, 1 light) 800x800 depth 1", 64),
+    "stock800": (lambda s: s.stock(800, 800), "brute", "unmodified v1 scene (24 triangles, 1 light) 800x800 depth 1", 64),
     "mirrors4k": (lambda s: s.mirrors(3840, 2160, 16), "brute", "facing mirrors 3840x2160 depth 16", 32),
-    "spheres800": (lambda s: s.spheres(20, 4, 800, 800), "lbvh", "20 icospheres x 5120 + room = 102412 triangles, 800x800, LBVH", 32),
+    "spheres800": (lambda s: s.spheres(20, 4, 800, 800), "lbvh", "20 icospheres x 5120 + room = 102412 triangles, 800x800, LBVH", 64),
     "spheres4k": (lambda s: s.spheres(20, 4, 3840, 2160), "lbvh", "102412 triangles, 3840x2160, LBVH", 32),
     "sweep8k": (lambda s: s.room(7680, 4320), "brute", "README room scene 7680x4320, 64-pose camera path", 8),
     "sweep8k_spheres": (lambda s: s.spheres(20, 4, 7680, 4320), "lbvh", "102412 triangles 7680x4320, 64-pose camera path, LBVH", 8),
@@ -74,7 +74,7 @@ def parse():
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
                     help="default: room800 on one GPU, sweep8k (row tiles + gather) on several")
     ap.add_argument("--tiles-per-wave", type=int, default=0)
-    ap.add_argument("--frames-per-launch", type=int, default=0, help="frames per launch (= per step); 0: the workload's own (32; 8 at 8K)")
+    ap.add_argument("--frames-per-launch", type=int, default=0, help="frames per launch (= per step); 0: the workload's own (64 at 800x800, 32 at 4K, 8 at 8K)")
     ap.add_argument("--size", type=int, nargs=2, default=None, help="override the workload's frame size (experiments)")
     ap.add_argument("--traversal", default="auto", choices=["auto", "per-lane", "packet"])
     ap.add_argument("--kernel", default="auto", choices=["auto", "state-machine", "lockstep"], help="form of the brute-force render kernel (rt_scene_set_kernel)")
@@ -200,7 +200,7 @@ class Workload:
             desc = desc.with_size(args.size[0], args.size[1])
             label += " [size overridden to %dx%d]" % tuple(args.size)
         self.desc, self.accel_name, self.label = desc, accel_name, label
-        self.fpl = max(1, min(32, frames_per_launch or args.frames_per_launch or fpl))
+        self.fpl = max(1, min(64, frames_per_launch or args.frames_per_launch or fpl))
         self.W, self.H, self.D = desc.width, desc.height, desc.depth
         self.scene = api.Scene.from_desc(desc)
         self.scene.set_traversal({"auto": api.TRAVERSAL_AUTO, "per-lane": api.TRAVERSAL_PER_LANE, "packet": api.TRAVERSAL_PACKET}[args.traversal])

@@ -213,7 +213,7 @@ int rt_render_device(rt_scene* s, int device, const float cam_pos[3], const floa
  * call returns); frame f lands at d_out_rgb + f * frame_stride_floats, each in the usual layout.
  * A single 800x800 frame is ~10 wavefronts per SIMD, too few to fill an MI355X; batching frames
  * removes the per-launch ramp and tail.  Pixels are identical to rt_render's. */
-#define RT_MAX_FRAMES_PER_LAUNCH 32
+#define RT_MAX_FRAMES_PER_LAUNCH 64
 int rt_render_frames_device(rt_scene* s, int device, int n_frames, const float* cam_pos3, const float* trans16,
                             int width, int height, int max_bounces, int render_flags,
                             float* d_out_rgb, size_t frame_stride_floats, void* hip_stream);

@@ -114,7 +114,7 @@ struct DevScene {
 // One launch may render several frames of the same scene (a camera path: consecutive iterations
 // of the frame loop, Source.cpp:1126, with known poses): workgroups [f * blocks_per_frame,
 // (f+1) * blocks_per_frame) render frame f into out + f * frame_stride.
-#define RT_MAX_FRAMES 32      /* 1.5 KB of poses in the kernel arguments (4 KB limit) */
+#define RT_MAX_FRAMES 64      /* 3 KB of poses in the kernel arguments (4 KB limit; DevScene + the rest of FrameParams are 0.35 KB) */
 struct FrameParams {
 	// per frame: camera.position (Source.cpp:545), then what Source.cpp:537-545 needs of trans
 	// (Source.cpp:1145-1147, column-major): columns 0 and 1, and c = m2 * 0.5f + m3 * 1.0f, the part of

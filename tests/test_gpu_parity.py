@@ -335,15 +335,15 @@ def test_recommit_after_edit():
 
 def test_frame_batch_equals_single_frames():
     """rt_render_frames_device: several camera poses in one launch give the same bits as one
-    rt_render per pose (40 poses = two launches of up to RT_MAX_FRAMES_PER_LAUNCH)."""
+    rt_render per pose (70 poses = two launches of up to RT_MAX_FRAMES_PER_LAUNCH = 64; 64 = exactly one)."""
     import torch
     desc = scenes.room(120, 88)
-    cams, trs = api.camera_sweep(40, desc.cam_pos, desc.cam_rot)
+    cams, trs = api.camera_sweep(70, desc.cam_pos, desc.cam_rot)
     n = desc.width * desc.height * 3
     with api.Scene.from_desc(desc) as sc:
         sc.commit(0, api.ACCEL_BRUTE)
-        singles = [sc.render(cams[i], trs[i], desc.width, desc.height, desc.depth) for i in range(40)]
-        for count, stride in [(1, n), (3, n + 64), (40, n)]:
+        singles = [sc.render(cams[i], trs[i], desc.width, desc.height, desc.depth) for i in range(70)]
+        for count, stride in [(1, n), (3, n + 64), (40, n), (64, n), (70, n + 8)]:
             buf = torch.full((count * stride,), -1.0, dtype=torch.float32, device="cuda:0")
             sc.render_frames_device(0, cams[:count], trs[:count], desc.width, desc.height, desc.depth, api.STRICT,
                                     buf.data_ptr(), stride, torch.cuda.current_stream().cuda_stream)
@@ -352,7 +352,7 @@ def test_frame_batch_equals_single_frames():
             for i in range(count):
                 assert np.array_equal(_bits(got[i, :n].reshape(desc.height, desc.width, 3)), _bits(singles[i])), (count, i)
                 assert np.all(got[i, n:] == -1.0)
-    assert not np.array_equal(singles[0], singles[39])
+    assert not np.array_equal(singles[0], singles[69])
 
 
 def test_controller_path_frames_vs_oracle(oracle):
