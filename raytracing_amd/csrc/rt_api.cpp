@@ -76,6 +76,7 @@ void free_device_state(DeviceState& d) {
 		if (d.render_stream) (void)hipStreamSynchronize(d.render_stream);
 		if (d.render_stream2) (void)hipStreamSynchronize(d.render_stream2);
 		if (d.copy_stream) (void)hipStreamSynchronize(d.copy_stream);
+		for (hipStream_t ms : d.multi_streams) if (ms) { (void)hipStreamSynchronize(ms); (void)hipStreamDestroy(ms); }
 		for (auto& b : d.vis_bufs) { if (b.vis) (void)hipFree(b.vis); if (b.meta) (void)hipFree(b.meta); if (b.hmask) (void)hipFree(b.hmask); }
 		if (d.planes) (void)hipFree(d.planes);
 		if (d.lights) (void)hipFree(d.lights);
@@ -816,10 +817,9 @@ int rt_render_multi(rt_scene* s, const int* devices, int n_devices, const float 
 	std::vector<void*> extra((size_t)n_devices, nullptr);          // shard buffers of a non-root device's second, third ... listing
 	auto cleanup = [&]() {
 		for (int k = 0; k < n_devices; k++) {
-			if (streams[k] || landed[k] || extra[k]) (void)hipSetDevice(devices[k]);
+			if (landed[k] || extra[k]) (void)hipSetDevice(devices[k]);
 			if (extra[k]) (void)hipFree(extra[k]);
-			if (landed[k]) (void)hipEventDestroy(landed[k]);
-			if (streams[k]) (void)hipStreamDestroy(streams[k]);
+			if (landed[k]) (void)hipEventDestroy(landed[k]);          // (the streams stay with their devices' states)
 		}
 	};
 	int prev = -1;
@@ -841,7 +841,13 @@ int rt_render_multi(rt_scene* s, const int* devices, int n_devices, const float 
 		DeviceState& d = s->dev[devices[k]];
 		const int rows = rt_shard_rows(height, tile_rows, k, n_devices);
 		if (hipSetDevice(devices[k]) != hipSuccess) { rc = RT_ERR_DEVICE; set_error("rt_render_multi: hipSetDevice(%d) failed", devices[k]); break; }
-		if (hipStreamCreateWithFlags(&streams[k], hipStreamNonBlocking) != hipSuccess) { rc = RT_ERR_DEVICE; set_error("rt_render_multi: stream creation failed"); break; }
+		{   // this listing's stream on its device: made once, kept (a new stream per call would also use up the per-stream scratch slots)
+			size_t nth = 0;
+			for (int a = 0; a < k; a++) nth += devices[a] == devices[k];
+			try { if (d.multi_streams.size() <= nth) d.multi_streams.resize(nth + 1, nullptr); } catch (...) { rc = RT_ERR_NOMEM; set_error("rt_render_multi: out of host memory"); break; }
+			if (!d.multi_streams[nth] && hipStreamCreateWithFlags(&d.multi_streams[nth], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); rc = RT_ERR_DEVICE; set_error("rt_render_multi: stream creation failed"); break; }
+			streams[k] = d.multi_streams[nth];
+		}
 		if (hipEventCreateWithFlags(&landed[k], hipEventDisableTiming) != hipSuccess) { rc = RT_ERR_DEVICE; set_error("rt_render_multi: event creation failed"); break; }
 		if (rows > 0) {
 			float* target = (float*)(area + (size_t)k * pitch);          // devices[0] renders where the shard belongs

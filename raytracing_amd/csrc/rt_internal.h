@@ -211,6 +211,7 @@ struct DeviceState {
 	// rt_render_async: two device frames, a render and a copy stream, per slot "rendered" / "copied" events
 	void* aframe[2] = { nullptr, nullptr };
 	size_t aframe_bytes[2] = { 0, 0 };
+	std::vector<hipStream_t> multi_streams;   // rt_render_multi: one per listing of this device, kept between calls (streams also key the per-stream scratch)
 	hipStream_t render_stream = nullptr, render_stream2 = nullptr, copy_stream = nullptr;   // (slot 0 renders on the first, slot 1 on the second: the ramp and tail of consecutive frames overlap)
 	hipEvent_t rendered[2] = { nullptr, nullptr }, copied[2] = { nullptr, nullptr };
 	long long ticket_of_slot[2] = { -1, -1 };

@@ -73,3 +73,9 @@ def test_render_multi_tree_scene_with_repeated_device():
         for devices, tile_rows in (([0, 0], 16), ([0] * 4, 8), ([0] * 7, 16)):
             multi = sc.render_multi(devices, desc.cam_pos, tr, 160, 120, desc.depth, tile_rows=tile_rows)
             assert np.array_equal(_bits(multi), _bits(whole)), (devices, tile_rows)
+        # many calls: the listings' streams (and their scratch) are kept between calls, and survive a re-commit
+        for k in range(12):
+            if k == 6:
+                sc.commit(0, api.ACCEL_LBVH)
+            multi = sc.render_multi([0, 0, 0], desc.cam_pos, tr, 160, 120, desc.depth, tile_rows=8)
+            assert np.array_equal(_bits(multi), _bits(whole)), k
