@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 wl=${1:-sweep8k}; shift
 for t in ${@:-0}; do
   rm -rf gpurun_out/wr_$t
-  timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/wr_$t -o p -- python3 bench.py --steps 4 --warmup 1 --no-cpu --no-configs --workload $wl --tiles-per-wave $t > gpurun_out/wr_$t.json 2>/dev/null || exit 1
+  timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/wr_$t -o p -- python3 bench.py --steps 4 --warmup 1 --no-cpu --no-configs --workload $wl --tiles-per-wave $t $EXTRA > gpurun_out/wr_$t.json 2>/dev/null || exit 1
   python3 - $t gpurun_out/wr_$t/p_counter_collection.csv gpurun_out/wr_$t.json <<'PY'
 import csv, sys, json
 t, f, j = sys.argv[1:4]
