@@ -1623,6 +1623,12 @@ static int pick_tiles_per_wave(int accel, long long tiles) {
 template <typename F> struct first_kernel_arg;
 template <typename A, typename... Rest> struct first_kernel_arg<void (*)(A, Rest...)> { typedef A type; };
 #define RT_SCENE_IS_FIRST_ARG(kernel) static_assert(std::is_same<first_kernel_arg<decltype(&kernel)>::type, DevScene>::value, #kernel ": DevScene must be the first kernel argument (scene_from_kernel_args)")
+template <typename F> struct second_kernel_arg;
+template <typename A, typename B, typename... Rest> struct second_kernel_arg<void (*)(A, B, Rest...)> { typedef B type; };
+// (frame_from_kernel_args / pose_from_kernel_args: FrameParams right behind it, as RenderKernelArgs lays them out)
+static_assert(std::is_same<second_kernel_arg<decltype(&render_lockstep_kernel<0, false, false>)>::type, FrameParams>::value &&
+              std::is_same<second_kernel_arg<decltype(&render_lockstep_kernel<3, true, false>)>::type, FrameParams>::value,
+              "render_lockstep_kernel: FrameParams must be the second kernel argument (frame_from_kernel_args)");
 RT_SCENE_IS_FIRST_ARG((render_kernel<0, false>));
 RT_SCENE_IS_FIRST_ARG((render_kernel<3, false>));
 RT_SCENE_IS_FIRST_ARG((render_lockstep_kernel<0, false, false>));
