@@ -390,17 +390,11 @@ __device__ __forceinline__ Hit cast_ray_pruned(const DevScene& sc, c4ptr tri, in
 // so ties go to the lower index explicitly (as in rt_lbvh_trav.inl).
 // COUNT: the work counters of SURVEY 8d for the lanes whose ray is still searching (lim >= 0) — what
 // the walk costs each ray it carries, in the units the per-lane traversal counts for itself.
-// A triangle record in LDS (the hoisted triangles, copied there per workgroup): the reads are broadcasts, the operands VGPRs
-struct l4ptr {
-	const float4* p;
-	__device__ __forceinline__ float4 operator[](unsigned int i) const { return p[i]; }
-};
-// How a trace handles the triangles kept out of the tree: behind their boxes (the default), or — by_mask — by the lanes' direction
-// masks hm (hoisted_by_mask), reading the records from the workgroup's LDS copy when there is one.
+// How a trace handles the triangles kept out of the tree: behind their boxes, or — by_mask — by the lanes' direction masks hm
+// (hoisted_by_mask).
 struct HoistCtx {
 	unsigned int hm = 0xffffffffu;
 	bool by_mask = false;
-	const float4* lds = nullptr;     // hoist_count records of RT_AOS_F4 float4, then hoist_count triangle indices (ints)
 };
 template <bool COUNT, typename Rec>
 __device__ __forceinline__ void packet_leaf(Rec T, int i, vec3 o, vec3 d, int skip, bool first_only,
@@ -454,7 +448,7 @@ __device__ __forceinline__ void wave_set_lane(int& v, int value, int lane) {
 // with what other lanes still hold.  Lanes with lim < 0 are done.
 template <bool COUNT>
 __device__ __forceinline__ void hoisted_by_mask(const DevScene& sc, unsigned int hm, vec3 o, vec3 d, int skip, bool first_only,
-                                                Hit& h, float& lim, float& lim_hi, LaneCounters& lc, WaveProf& wp, const float4* lds = nullptr) {
+                                                Hit& h, float& lim, float& lim_hi, LaneCounters& lc, WaveProf& wp) {
 	const c4ptr hrec = c4ptr_of(sc.hoist);
 	const c4ptr hbox = hrec.offset_floats((unsigned int)sc.hoist_count * (RT_AOS_F4 * 4u));     // (octant 0's boxes: the second float4 of record j ends with the triangle's index)
 	const float eps_lo = RT_EPS_BELOW * (1.0f - RT_PREFILTER_REL);
@@ -468,12 +462,11 @@ __device__ __forceinline__ void hoisted_by_mask(const DevScene& sc, unsigned int
 			const int j = __builtin_ctz(m);
 			m &= m - 1u;
 			if (j >= sc.hoist_count) break;
-			const int i = lds ? __builtin_amdgcn_readfirstlane(((const int*)(lds + sc.hoist_count * RT_AOS_F4))[j]) : __float_as_int(hbox[(unsigned int)j * 2u + 1u].w);
+			const int i = __float_as_int(hbox[(unsigned int)j * 2u + 1u].w);
 			const bool want = lim >= 0.0f && ((hm >> j) & 1u) != 0u && i != skip;
 			if (__builtin_amdgcn_ballot_w64(want) == 0ull) continue;
 			RT_PROF(wp, WP_INBOX);
-			if (lds) { l4ptr R; R.p = lds + j * RT_AOS_F4; packet_leaf<COUNT>(R, i, o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp); }
-			else packet_leaf<COUNT>(hrec.offset_floats((unsigned int)j * (RT_AOS_F4 * 4u)), i, o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp);
+			packet_leaf<COUNT>(hrec.offset_floats((unsigned int)j * (RT_AOS_F4 * 4u)), i, o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp);
 		}
 	}
 }
@@ -537,7 +530,7 @@ __device__ __forceinline__ Hit cast_ray_packet(const DevScene& sc, int oct, vec3
 	if (sc.debug & 16) return h;
 #endif
 	if (hc.by_mask) {
-		if (sc.hoist_count > 0) hoisted_by_mask<COUNT>(sc, hc.hm, o, d, skip, first_only, h, lim, lim_hi, lc, wp, hc.lds);
+		if (sc.hoist_count > 0) hoisted_by_mask<COUNT>(sc, hc.hm, o, d, skip, first_only, h, lim, lim_hi, lc, wp);
 	} else if (sc.hoist_count > 0 && __builtin_amdgcn_ballot_w64(lim >= 0.0f) != 0) {
 		const c4ptr hrec = c4ptr_of(sc.hoist);
 		const c4ptr hbox = hrec.offset_floats((unsigned int)sc.hoist_count * (RT_AOS_F4 * 4u) + (unsigned int)oct * (unsigned int)sc.hoist_count * 8u);
@@ -1036,7 +1029,7 @@ __device__ __forceinline__ Hit trace_kind(const DevScene& sc, const float* lds_n
 // made one (LBVH scenes, rt_lgrid.hip), through the tree or the brute-force loop otherwise.
 template <int ACCEL, bool COUNT>
 __device__ __forceinline__ Hit trace_shadow(const DevScene& sc_arg, const float* lds_num0, int li, vec3 L, vec3 o, vec3 d, int skip, bool live, float dist,
-                                            LaneCounters& lc, WaveProf& wp, const float4* lds_hoist = nullptr) {
+                                            LaneCounters& lc, WaveProf& wp) {
 #ifdef RT_EXPERIMENT
 	if (sc_arg.debug & 64) { Hit h; h.t = 1e9f; h.idx = -1; h.p = make3(0.f, 0.f, 0.f); return h; }     // (attribution: no shadow work at all)
 #endif
@@ -1044,8 +1037,8 @@ __device__ __forceinline__ Hit trace_shadow(const DevScene& sc_arg, const float*
 		if (li < sc_arg.n_lgrid) {
 			const __attribute__((address_space(4))) LightGrid* G = (const __attribute__((address_space(4))) LightGrid*)(unsigned long long)(sc_arg.lgrid + li);
 			if (G->R > 0) {
-				if constexpr (ACCEL == 3) return grid_shadow<COUNT>(scene_from_kernel_args(sc_arg), li, L, o, d, skip, live, dist, lc, wp, lds_hoist);
-				else return grid_shadow<COUNT>(sc_arg, li, L, o, d, skip, live, dist, lc, wp, lds_hoist);
+				if constexpr (ACCEL == 3) return grid_shadow<COUNT>(scene_from_kernel_args(sc_arg), li, L, o, d, skip, live, dist, lc, wp);
+				else return grid_shadow<COUNT>(sc_arg, li, L, o, d, skip, live, dist, lc, wp);
 			}
 		}
 	}
@@ -1332,7 +1325,6 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 	float* s_num0 = (float*)s_tri;
 	// (A copy of the hoisted triangles' records in LDS, read by broadcast instead of through the scalar cache, was measured SLOWER:
 	// 102k triangles 3840x2160 213.6 against 199.8 us/frame — the records then sit in vector registers the kernel does not have.)
-	const float4* lds_hoist = nullptr;
 	int frame = fp.n_frames > 1 ? (int)(blockIdx.x / fp.blocks_per_frame) : 0;      // workgroup-uniform
 	unsigned int block_in_frame = blockIdx.x - (unsigned int)frame * fp.blocks_per_frame;
 	if constexpr (ACCEL == 2 || ACCEL == 3) {
@@ -1406,7 +1398,6 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 		vec3 d, cam_t = cam;
 		Hit h;
 		HoistCtx hc;
-		hc.lds = lds_hoist;
 		{
 			float m[12];
 			pose_from_kernel_args(fp, frame, m);
@@ -1484,7 +1475,7 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 				const float inv = 1.0f / s;                                  // glm::normalize: v * inversesqrt(dot(v,v))
 				const vec3 ld = ray * inv;
 				if constexpr (COUNT) ctr[CTR_SHADOW] += shade;
-				const Hit sh = trace_shadow<ACCEL, COUNT>(sc, s_num0, li, make3(L.x, L.y, L.z), hp, ld, hidx, shade, s, lc, wp, lds_hoist);   // Source.cpp:473
+				const Hit sh = trace_shadow<ACCEL, COUNT>(sc, s_num0, li, make3(L.x, L.y, L.z), hp, ld, hidx, shade, s, lc, wp);   // Source.cpp:473
 				if (shade && (!(sh.idx >= 0) || sh.t > s)) {                 // Source.cpp:476
 					lit_any = true;
 					const float f = 1.0f / (s * s) * L.w;                    // Source.cpp:488

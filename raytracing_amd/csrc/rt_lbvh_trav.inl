@@ -73,7 +73,7 @@ __device__ __forceinline__ Hit cast_ray_lbvh(const DevScene& sc, int* lds_stack,
 	if (sc.hoist_count > 0) {
 		if (hc.by_mask) {                                                   // (rt_kernels.hip hoisted_by_mask: by the lanes' direction masks, no boxes)
 			float l2 = live ? lim : -1.0f, l2_hi = l2 + fabsf(l2) * RT_PREFILTER_REL;
-			hoisted_by_mask<COUNT>(sc, hc.hm, o, d, skip, shadow, h, l2, l2_hi, lc, wp, hc.lds);
+			hoisted_by_mask<COUNT>(sc, hc.hm, o, d, skip, shadow, h, l2, l2_hi, lc, wp);
 			if (live) { lim = l2; lim_hi = l2_hi; }
 		} else hoisted_tests<COUNT>(sc, o, d, s.inv, s.oi, skip, live, shadow, h, lim, lim_hi, lc, wp);
 		walk = live && lim >= 0.0f;                                      // a shadow ray that has its hit is done

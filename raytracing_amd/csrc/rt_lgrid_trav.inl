@@ -43,8 +43,7 @@ __device__ __forceinline__ void lane_triangle_any_hit(const DevScene& sc, int i,
 // li: wave-uniform light index with a grid (G.R > 0).  L: that light's position.  `live` lanes hold a shadow ray from o
 // along d = normalize(L - o), dist = |L - o| (Source.cpp:470-474).
 template <bool COUNT>
-__device__ __forceinline__ Hit grid_shadow(const DevScene& sc, int li, vec3 L, vec3 o, vec3 d, int skip, bool live, float dist, LaneCounters& lc, WaveProf& wp,
-                                           const float4* lds_hoist = nullptr) {
+__device__ __forceinline__ Hit grid_shadow(const DevScene& sc, int li, vec3 L, vec3 o, vec3 d, int skip, bool live, float dist, LaneCounters& lc, WaveProf& wp) {
 	Hit h;
 	h.t = 1e9f;
 	h.idx = -1;
@@ -127,8 +126,7 @@ __device__ __forceinline__ Hit grid_shadow(const DevScene& sc, int li, vec3 L, v
 				const int i = G->hidx[j];
 				const bool want = lim >= 0.0f && ((hm >> j) & 1u) != 0u && G->hmind[j] <= far && i != skip;
 				if (__builtin_amdgcn_ballot_w64(want) == 0ull) continue;
-				if (lds_hoist) { l4ptr R; R.p = lds_hoist + j * RT_AOS_F4; packet_leaf<COUNT>(R, i, o, d, skip, true, eps_lo, h, lim, lim_hi, lc, wp); }
-				else packet_leaf<COUNT>(hrec.offset_floats((unsigned int)j * (RT_AOS_F4 * 4u)), i, o, d, skip, true, eps_lo, h, lim, lim_hi, lc, wp);
+				packet_leaf<COUNT>(hrec.offset_floats((unsigned int)j * (RT_AOS_F4 * 4u)), i, o, d, skip, true, eps_lo, h, lim, lim_hi, lc, wp);
 			}
 		}
 	}

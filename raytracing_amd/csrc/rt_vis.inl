@@ -232,7 +232,7 @@ __device__ __forceinline__ Hit trace_primary_vis(const DevScene& sc_arg, const F
 	if (sc.debug & 4) return h;
 #endif
 	if (sc.hoist_count > 0) {
-		if (hc.by_mask) hoisted_by_mask<COUNT>(sc, hc.hm, o, d, -1, false, h, lim, lim_hi, lc, wp, hc.lds);
+		if (hc.by_mask) hoisted_by_mask<COUNT>(sc, hc.hm, o, d, -1, false, h, lim, lim_hi, lc, wp);
 		else hoisted_tests<COUNT>(sc, o, d, inv, oi, -1, live, false, h, lim, lim_hi, lc, wp);
 	}
 	return h;
