@@ -1595,7 +1595,7 @@ static bool use_packets_cols(const DevScene& sc, const float col0[3], const floa
 	const float du = sqrtf(col0[0] * col0[0] + col0[1] * col0[1] + col0[2] * col0[2]) / (float)(width > 0 ? width : 1);
 	const float dv = sqrtf(col1[0] * col1[0] + col1[1] * col1[1] + col1[2] * col1[2]) / (float)(height > 0 ? height : 1);
 	const float footprint = 8.0f * 0.5f * (du + dv) * sc.packet_scale;
-	return footprint < 5.5f;
+	return footprint < 6.0f;
 }
 
 static int pick_tiles_per_wave(int accel, long long tiles) {
@@ -1650,23 +1650,14 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 	const long long tiles_x = (fp.width + RT_TILE_W - 1) / RT_TILE_W, tiles_y = (fp.local_rows + RT_TILE_H - 1) / RT_TILE_H;
 	const bool column_runs = lockstep && accel != RT_ACCEL_LBVH;
 	const long long waves = column_runs ? tiles_x * ((tiles_y + tpw - 1) / tpw) : (tiles + tpw - 1) / tpw;
-#ifdef RT_EXPERIMENT
-	static const int env_block = [] { const char* e = getenv("RT355_BLOCK_THREADS"); int v = e ? atoi(e) : 0; return (v == 64 || v == 128 || v == 256) ? v : 0; }();
-	const int threads = env_block ? env_block : 256;
-#else
-	const int threads = 256;
-#endif
-	const int wpb = threads / 64;
-	const long long blocks = (waves + wpb - 1) / wpb;
-	if (blocks * n_frames > 0x7fffffffLL) { set_error("rt_render: frame too large (%lld workgroups)", blocks * n_frames); return RT_ERR_LIMIT; }
-	fp.n_frames = n_frames;
-	fp.blocks_per_frame = (unsigned int)blocks;
 	// LBVH: walk the tree once per wavefront ("packet") when an 8x8 tile of rays is coherent against the
 	// scene's triangles, per lane otherwise.  Footprint of a tile at the far side of the scene in units
 	// of the mean triangle size; measured on the 100k-triangle scene (round 3: clustered tree, shadow rays through the light's
 	// grid, so only primary and bounce rays differ), us/frame packets | per lane: 300x300 (footprint 12.3) 17.6 | 7.7, 400 (9.2)
 	// 18.4 | 10.9, 500 (7.4) 20.4 | 15.5, 600 (6.1) 21.0 | 18.7, 800 (4.6) 26.4 | 29.0, 1000 (3.7) 34.3 | 41.6, 1200 (3.1) 44.4 | 55.9,
-	// 1600 (2.3) 67.9 | 90.5, 2400 (1.5) 127.5 | 183.5, 3840x2160 (1.3) 172.1 | 244.7: packets below a footprint of 5.5.
+	// 1600 (2.3) 67.9 | 90.5, 2400 (1.5) 127.5 | 183.5, 3840x2160 (1.3) 172.1 | 244.7: packets below a footprint of 5.5.  Re-measured
+	// with 64 frames per launch and workgroups of one wavefront: 300 11.4 | 5.2, 400 11.3 | 7.5, 500 11.9 | 10.3, 600 (6.1) 13.5 | 13.3,
+	// 700 (5.3) 16.0 | 17.2, 800 18.9 | 21.3, 1000 24.9 | 30.3: packets below 6.
 	DevScene sc_sel = sc;
 	if (accel == RT_ACCEL_LBVH) {
 		bool packets = use_packets_cols(sc, fp.pose[0] + 3, fp.pose[0] + 6, fp.width, fp.height);
@@ -1678,6 +1669,24 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 		if (packets && !count && sc.traversal == RT_TRAVERSAL_AUTO && sc.per_lane_ok && tiles * n_frames < 90000) packets = false;
 		if (!packets) sc_sel.skip_count = 0;
 	}
+	// Workgroups of ONE wavefront for the tree kernels (no barrier in them; the per-lane walk's LDS stack is laid out for 64 lanes,
+	// RT_STACK_PITCH): a workgroup's resources are released when its last wave ends, and the walks of four tiles differ in
+	// length — measured, 102k triangles, packets, workgroups of 256 | 128 | 64 threads: 800x800 22.1 | 21.2 | 19.6 us/frame
+	// (wavefronts resident per SIMD 5.2 of 8 with 256), 3840x2160 155.1 | 154.4 | 153.3.  Brute force fills a numerator table in LDS
+	// per workgroup (one value per triangle) and gains about 1 % — two runs each, 256 | 64 threads: room 800x800 10.66, 10.73 | 10.53,
+	// 10.55, stock 7.49, 7.53 | 7.41, 7.44, mirrors 4K 213.4, 214.3 | 212.2, 212.8, room 8K 518.6, 520.6 | 514.6, 516.6 — so scenes of up
+	// to 256 triangles (a table of 1 KB) get one-wave workgroups too; larger forced-brute scenes keep 256.
+#ifdef RT_EXPERIMENT
+	static const int env_block = [] { const char* e = getenv("RT355_BLOCK_THREADS"); int v = e ? atoi(e) : 0; return (v == 64 || v == 128 || v == 256) ? v : 0; }();
+	const int threads = (accel == RT_ACCEL_LBVH) ? 64 : (env_block ? env_block : (sc.n_tris <= 256 ? 64 : 256));
+#else
+	const int threads = (accel == RT_ACCEL_LBVH || sc.n_tris <= 256) ? 64 : 256;
+#endif
+	const int wpb = threads / 64;
+	const long long blocks = (waves + wpb - 1) / wpb;
+	if (blocks * n_frames > 0x7fffffffLL) { set_error("rt_render: frame too large (%lld workgroups)", blocks * n_frames); return RT_ERR_LIMIT; }
+	fp.n_frames = n_frames;
+	fp.blocks_per_frame = (unsigned int)blocks;
 	dim3 grid((unsigned)(blocks * n_frames)), block((unsigned)threads);
 	// XCD-aware workgroup order for multi-frame LBVH launches (rt_internal.h FrameParams::band_blocks).
 	// Measured on the 100k-triangle scene, 32 frames per launch, us/frame without | with: 800x800 76 | 72
@@ -1687,9 +1696,9 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 	fp.band_blocks = 0;
 #ifdef RT_EXPERIMENT
 	static const int env_bands = [] { const char* e = getenv("RT355_XCD_BANDS"); return e ? atoi(e) : -1; }();   // 0 off, 1 always
-	const bool bands = env_bands >= 0 ? env_bands != 0 : blocks <= 24000;
+	const bool bands = env_bands >= 0 ? env_bands != 0 : waves <= 96000;
 #else
-	const bool bands = blocks <= 24000;
+	const bool bands = waves <= 96000;
 #endif
 #ifdef RT_EXPERIMENT
 	static const int band_min_frames = [] { const char* e = getenv("RT355_BAND_MIN_FRAMES"); return e ? atoi(e) : 8; }();
@@ -1741,7 +1750,7 @@ int launch_cast_rays(const DevScene& sc, int accel, int n, const float* d_rays7,
 		DevScene sc_sel = sc;
 		if (sc.traversal != RT_TRAVERSAL_PACKET && sc.per_lane_ok) sc_sel.skip_count = 0;   // ray batches are per lane unless packets are asked for
 		if (sc_sel.skip_count > 0) hipLaunchKernelGGL((cast_rays_kernel<3>), grid, block, 0, stream, sc_sel, n, d_rays7, d_out6);
-		else hipLaunchKernelGGL((cast_rays_kernel<2>), grid, block, (size_t)RT_STACK_LDS * 256 * sizeof(int), stream, sc_sel, n, d_rays7, d_out6);
+		else hipLaunchKernelGGL((cast_rays_kernel<2>), dim3((unsigned)((n + 63) / 64)), dim3(64), (size_t)RT_STACK_LDS * RT_STACK_PITCH * sizeof(int), stream, sc_sel, n, d_rays7, d_out6);   // (one wavefront per workgroup: RT_STACK_PITCH)
 	} else if (sc.n_tris <= RT_LDS_MAX_TRIS) {
 		const size_t lds = (size_t)lds_stride_of(sc.n_tris) * sizeof(float);
 		hipLaunchKernelGGL((cast_rays_kernel<0>), grid, block, lds, stream, sc, n, d_rays7, d_out6);

@@ -29,7 +29,7 @@
 #ifndef RT_LEAF_MIN
 #define RT_LEAF_MIN 1        /* lanes that must be waiting on a parked leaf before the wave makes a leaf trip */
 #endif
-#define RT_STACK_PITCH 256   /* lanes per workgroup the LDS stack is laid out for */
+#define RT_STACK_PITCH 64    /* lanes per workgroup the LDS stack is laid out for: every kernel that walks per lane is launched in workgroups of one wavefront (rt_kernels.hip launch_render) */
 
 namespace rt {
 
