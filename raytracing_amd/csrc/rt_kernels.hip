@@ -637,6 +637,9 @@ __device__ __forceinline__ float exit_bound(const DevScene& sc, vec3 o, vec3 d) 
 // 25-bit midpoint needs 39+ significant bits, x has 24), while the two binary64 roundings move it by
 // 2^-52 at most, so both round to the same binary32.  Checked exhaustively, bit for bit, over all 2^31
 // non-negative binary32 values and +inf against the binary64 form.
+#ifndef RT_NT_STORE
+#define RT_NT_STORE 0
+#endif
 #ifndef RT_DIV65025_FAST
 #define RT_DIV65025_FAST 0
 #endif
@@ -665,10 +668,25 @@ __device__ __forceinline__ unsigned int unorm8(float c) {
 __device__ __forceinline__ void store_pixel(const FrameParams& fp, int frame, long long pixel, vec3 c) {
 	if (fp.rgba8) {
 		unsigned int* out = (unsigned int*)fp.out + (long long)frame * fp.frame_stride + pixel;
-		*out = unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16) | 0xff000000u;
+		const unsigned int px = unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16) | 0xff000000u;
+#if RT_NT_STORE
+		__builtin_nontemporal_store(px, out);
+#else
+		*out = px;
+#endif
 	} else {
 		float* out = fp.out + (long long)frame * fp.frame_stride + pixel * 3;   // Source.cpp:550
+#if RT_NT_STORE
+		// Source.cpp:612-614 as streaming stores (off; -DRT_NT_STORE=1 to try): a frame is written once and never read by the kernel,
+		// and at 100 MB (3840x2160) it pushes the scene out of the L2s it passes through.  Measured plain | streaming, us/frame: 102k
+		// triangles 800x800 18.85 | 18.35, 3840x2160 139.6 | 138.8, 7680x4320 512.8 | 498.7; room 800x800 10.52 | 10.46, 7680x4320 520.0 |
+		// 520.1 — but the 128-byte lines that two tiles of a tree kernel share then go to memory twice: WRITE_SIZE / frame bytes 1.00 ->
+		// 1.33 at 800x800, 1.43 at 3840x2160, 1.04 -> 1.11 at 7680x4320 (brute force, whose runs go down a column, stays at 1.000).
+		// Up to 2.7 % of time against 11-43 % more bytes written: left off.
+		__builtin_nontemporal_store(c.x, out); __builtin_nontemporal_store(c.y, out + 1); __builtin_nontemporal_store(c.z, out + 2);
+#else
 		out[0] = c.x; out[1] = c.y; out[2] = c.z;                               // Source.cpp:612-614
+#endif
 	}
 }
 
@@ -1643,9 +1661,11 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 	const bool lockstep = !count && lockstep_form;
 	int tpw = fp.tiles_per_wave > 0 ? fp.tiles_per_wave : (lockstep && accel != RT_ACCEL_LBVH ? (tiles * n_frames >= 128 * 8192 ? 2 * RT_LOCKSTEP_TILES : (tiles * n_frames >= 16 * 8192 ? RT_LOCKSTEP_TILES : (tiles * n_frames >= 4 * 8192 ? 2 : 1)))
 	                                                                                           : pick_tiles_per_wave(accel, tiles * n_frames));
-	// (tree kernels: one tile, except frames of 400k tiles and more — 102k triangles, measured 1 | 2 tiles: 3840x2160 214.6 | 222.7 us,
-	// 7680x4320 799 | 773)
-	if (fp.tiles_per_wave <= 0 && lockstep && accel == RT_ACCEL_LBVH && tiles >= 400000) tpw = 2;
+	// (tree kernels: one tile, except long launches of large frames, where the next tile along the row walks nearly the same nodes
+	// while they are still in the caches — 102k triangles, us/frame at 1 | 2 | 3 tiles: 800x800 19.0 | 21.1 | 22.3, 1200x1200 32.6 | 32.4 |
+	// 32.9, 1600x1600 50.7 | 50.1 | 49.7, 2000x2000 73.3 | 70.6 | 70.3, 2400x2400 100.7 | 95.9 | 96.9, 3840x2160 140.7 | 134.4 | 134.3,
+	// 7680x4320 541.2 | 514.8 | 511.5; round 2's kernels had 3840x2160 at 214.6 | 222.7 and the rule began at 400k tiles a frame)
+	if (fp.tiles_per_wave <= 0 && lockstep && accel == RT_ACCEL_LBVH && tiles >= 40000 && tiles * n_frames >= 400000) tpw = 2;
 	// (the brute-force lockstep kernels run a wave's tiles down a column: whole columns of ceil(tile rows / tpw) bands; the others along rows)
 	const long long tiles_x = (fp.width + RT_TILE_W - 1) / RT_TILE_W, tiles_y = (fp.local_rows + RT_TILE_H - 1) / RT_TILE_H;
 	const bool column_runs = lockstep && accel != RT_ACCEL_LBVH;
@@ -1691,14 +1711,19 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 	// XCD-aware workgroup order for multi-frame LBVH launches (rt_internal.h FrameParams::band_blocks).
 	// Measured on the 100k-triangle scene, 32 frames per launch, us/frame without | with: 800x800 76 | 72
 	// (L2 misses per wavefront 39 -> 28), 1000x1000 101 | 91, 1600x1600 168 | 161, 2400x2400 305 | 287;
-	// wide and very large frames do not gain (3200x1800 295 | 294, 3840x2160 387 | 397, 7680x4320 1364 | 1365:
-	// a band of full-width rows already spans most of the scene), hence the size limit.
+	// wide and very large frames did not gain with round 2's kernels (3200x1800 295 | 294, 3840x2160 387 | 397, 7680x4320 1364 | 1365:
+	// a band of full-width rows already spans most of the scene) and had a size limit; with round 3's (a third of the time per
+	// frame, the same misses) they do — 3840x2160 153.2 | 149.2 and 153.6 | 150.0, 7680x4320 552.8 | 549.6 and 553.8 | 550.4, 800x800
+	// 19.6 | 19.5 — so every size gets the bands.  RECTANGLES of tiles per XCD (4 x 2, nearer to square than bands of rows) were
+	// slower: 3840x2160 157.7, 7680x4320 569.8, 800x800 19.7 (scripts/bands_sweep.sh, experiment build); so was an XCD that stays on
+	// its band for 2 | 4 | 8 frames before moving on (its L2 would keep that part of the scene): 3840x2160 149.7 -> 151.9 | 158.8 |
+	// 165.7, 7680x4320 551.6 -> 607.7 | 666.1 | 736.9 — bands differ in cost, and the rotation with every frame is what evens them out.
 	fp.band_blocks = 0;
 #ifdef RT_EXPERIMENT
 	static const int env_bands = [] { const char* e = getenv("RT355_XCD_BANDS"); return e ? atoi(e) : -1; }();   // 0 off, 1 always
-	const bool bands = env_bands >= 0 ? env_bands != 0 : waves <= 96000;
+	const bool bands = env_bands >= 0 ? env_bands != 0 : true;
 #else
-	const bool bands = waves <= 96000;
+	const bool bands = true;
 #endif
 #ifdef RT_EXPERIMENT
 	static const int band_min_frames = [] { const char* e = getenv("RT355_BAND_MIN_FRAMES"); return e ? atoi(e) : 8; }();

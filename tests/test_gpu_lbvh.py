@@ -159,24 +159,27 @@ def test_frame_batches_through_the_tree_equal_single_frames():
     (rt_kernels.hip launch_render): every frame of the batch must still be the frame rt_render gives
     for its pose, with both traversals, for frame sizes whose last band is padded."""
     import torch
-    for (w, h) in ((120, 88), (67, 45)):
+    for (w, h) in ((120, 88), (67, 45), (200, 40), (40, 200)):           # 165, 54, 125 and 125 tiles in 8 bands: the last band is padded in each
         desc = scenes.spheres(3, 2, w, h, depth=2)
         cams, trs = api.camera_sweep(19, desc.cam_pos, desc.cam_rot)
         n = w * h * 3
         with api.Scene.from_desc(desc) as sc:
             sc.commit(0, api.ACCEL_LBVH)
-            for mode, kind in ((api.TRAVERSAL_PER_LANE, api.KERNEL_AUTO), (api.TRAVERSAL_PACKET, api.KERNEL_LOCKSTEP),
-                               (api.TRAVERSAL_PACKET, api.KERNEL_STATE_MACHINE)):
+            for mode, kind, tpw in ((api.TRAVERSAL_PER_LANE, api.KERNEL_AUTO, 0), (api.TRAVERSAL_PACKET, api.KERNEL_LOCKSTEP, 0),
+                                    (api.TRAVERSAL_PACKET, api.KERNEL_LOCKSTEP, 3), (api.TRAVERSAL_PER_LANE, api.KERNEL_LOCKSTEP, 2),
+                                    (api.TRAVERSAL_PACKET, api.KERNEL_STATE_MACHINE, 0)):
                 sc.set_traversal(mode)
                 sc.set_kernel(kind)
+                sc.set_tiles_per_wave(0)
                 singles = [sc.render(cams[i], trs[i], w, h, desc.depth) for i in range(19)]
+                sc.set_tiles_per_wave(tpw)                               # (runs of tiles that cross a band's edge)
                 buf = torch.full((19 * n,), -1.0, dtype=torch.float32, device="cuda:0")
                 sc.render_frames_device(0, cams, trs, w, h, desc.depth, api.STRICT, buf.data_ptr(), n,
                                         torch.cuda.current_stream().cuda_stream)
                 torch.cuda.synchronize()
                 got = buf.cpu().numpy().reshape(19, h, w, 3)
                 for i in range(19):
-                    assert np.array_equal(_bits(got[i]), _bits(singles[i])), (w, h, mode, kind, i)
+                    assert np.array_equal(_bits(got[i]), _bits(singles[i])), (w, h, mode, kind, tpw, i)
         assert not np.array_equal(singles[0], singles[18])
 
 
