@@ -1364,21 +1364,25 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 	}
 	const int tiles_x = (fp.width + RT_TILE_W - 1) / RT_TILE_W;
 	const int tiles_y = (fp.local_rows + RT_TILE_H - 1) / RT_TILE_H;
-	// Brute force: a wave's run of tiles goes DOWN a column of tiles — wave w has column w % tiles_x of the band of tiles_per_wave
-	// tile rows w / tiles_x.  The tiles left and right of it are then rendered by the neighbouring waves at about the same time,
-	// and the 128-byte lines two of them share (a tile row is 96 bytes of RGB) are completed in the L2 before it writes them back;
-	// with runs ALONG a row the halves of such a line were stored a tile's time apart and went to memory twice (measured, room
-	// 7680x4320, WRITE_SIZE / frame bytes at 1 | 2 | 4 | 8 tiles per wave: 1.000 | 1.008 | 1.035 | 1.079, now 1.000 throughout;
-	// scripts/write_ratio.sh).  The tree kernels keep runs along the row (theirs are one tile long, two at 8K: 1.04 there): the
-	// column form costs the packet kernel seven spilled vector registers, whose scratch traffic more than doubled its writes.
+	// A wave's run of tiles goes DOWN a column of tiles — wave w has column w % tiles_x of the band of tiles_per_wave tile rows
+	// w / tiles_x.  The tiles left and right of it are then rendered by the neighbouring waves at about the same time, and the
+	// 128-byte lines two of them share (a tile row is 96 bytes of RGB) are completed in the L2 before it writes them back; with
+	// runs ALONG a row the halves of such a line were stored a tile's time apart and went to memory twice (measured, room 7680x4320,
+	// WRITE_SIZE / frame bytes at 1 | 2 | 4 | 8 tiles per wave: 1.000 | 1.008 | 1.035 | 1.079, now 1.000 throughout;
+	// scripts/write_ratio.sh).  The tree kernels too: 102k triangles, two tiles per wave, along the row | down the column 3840x2160
+	// 134.0 | 132.3 us/frame with 1.048 | 1.01 of the frame's bytes written, 7680x4320 489 | 483 and 1.035 | 1.00.  (When the tile loop
+	// re-derived its position from the wave's number the column form cost the packet kernel seven spilled vector registers; with
+	// tx, ty and `left` carried along it has none and four spilled SGPRs fewer than the row form.)
 	const unsigned int wave = __builtin_amdgcn_readfirstlane(block_in_frame * (blockDim.x >> 6) + (threadIdx.x >> 6));
 	int tx, ty, left;                                                 // this wave's next tile, and how many it still has
-	if constexpr (ACCEL == 0 || ACCEL == 1) {
+	if constexpr (ACCEL != 2) {
 		const unsigned int band_of_wave = wave / (unsigned int)tiles_x;
 		tx = (int)(wave - band_of_wave * (unsigned int)tiles_x);
 		ty = (int)(band_of_wave * (unsigned int)tiles_per_wave);      // (tiles_per_wave <= 1024 and wave < 2^21: no wrap)
 		left = min(tiles_per_wave, tiles_y - ty);
 	} else {
+		// (the per-lane walk keeps runs along the row: down the column costs it four more spilled vector registers, 800x800 21.4 -> 21.8
+		// us/frame; it runs one tile per wave up to 8K anyway)
 		const unsigned int n_tiles = (unsigned int)tiles_x * (unsigned int)tiles_y;
 		const unsigned int tile = wave * (unsigned int)tiles_per_wave;
 		ty = (int)(tile / (unsigned int)tiles_x);
@@ -1410,7 +1414,7 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 		// 3840x2160 155 -> 147 us/frame; brute force +-0 on the room at 800x800, -1 % on the 4K mirrors and the 8K room)
 		const FrameParams fp_top = frame_from_kernel_args(fp);
 		const bool inside = (x < fp_top.width) && (ly < fp_top.local_rows);
-		if constexpr (ACCEL == 0 || ACCEL == 1) ty++;
+		if constexpr (ACCEL != 2) ty++;
 		else if (++tx == tiles_x) { tx = 0; ty++; }
 		// ---- primary ray (Source.cpp:534-548)
 		vec3 d, cam_t = cam;
@@ -1661,15 +1665,6 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 	const bool lockstep = !count && lockstep_form;
 	int tpw = fp.tiles_per_wave > 0 ? fp.tiles_per_wave : (lockstep && accel != RT_ACCEL_LBVH ? (tiles * n_frames >= 128 * 8192 ? 2 * RT_LOCKSTEP_TILES : (tiles * n_frames >= 16 * 8192 ? RT_LOCKSTEP_TILES : (tiles * n_frames >= 4 * 8192 ? 2 : 1)))
 	                                                                                           : pick_tiles_per_wave(accel, tiles * n_frames));
-	// (tree kernels: one tile, except long launches of large frames, where the next tile along the row walks nearly the same nodes
-	// while they are still in the caches — 102k triangles, us/frame at 1 | 2 | 3 tiles: 800x800 19.0 | 21.1 | 22.3, 1200x1200 32.6 | 32.4 |
-	// 32.9, 1600x1600 50.7 | 50.1 | 49.7, 2000x2000 73.3 | 70.6 | 70.3, 2400x2400 100.7 | 95.9 | 96.9, 3840x2160 140.7 | 134.4 | 134.3,
-	// 7680x4320 541.2 | 514.8 | 511.5; round 2's kernels had 3840x2160 at 214.6 | 222.7 and the rule began at 400k tiles a frame)
-	if (fp.tiles_per_wave <= 0 && lockstep && accel == RT_ACCEL_LBVH && tiles >= 40000 && tiles * n_frames >= 400000) tpw = 2;
-	// (the brute-force lockstep kernels run a wave's tiles down a column: whole columns of ceil(tile rows / tpw) bands; the others along rows)
-	const long long tiles_x = (fp.width + RT_TILE_W - 1) / RT_TILE_W, tiles_y = (fp.local_rows + RT_TILE_H - 1) / RT_TILE_H;
-	const bool column_runs = lockstep && accel != RT_ACCEL_LBVH;
-	const long long waves = column_runs ? tiles_x * ((tiles_y + tpw - 1) / tpw) : (tiles + tpw - 1) / tpw;
 	// LBVH: walk the tree once per wavefront ("packet") when an 8x8 tile of rays is coherent against the
 	// scene's triangles, per lane otherwise.  Footprint of a tile at the far side of the scene in units
 	// of the mean triangle size; measured on the 100k-triangle scene (round 3: clustered tree, shadow rays through the light's
@@ -1689,6 +1684,19 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 		if (packets && !count && sc.traversal == RT_TRAVERSAL_AUTO && sc.per_lane_ok && tiles * n_frames < 90000) packets = false;
 		if (!packets) sc_sel.skip_count = 0;
 	}
+	// (tree kernels: one tile, except long launches of large frames, where the next tile down the column walks nearly the same nodes
+	// while they are still in the caches — 102k triangles, us/frame at 1 | 2 | 3 | 4 | 6 tiles: 800x800 19.0 | 19.8, 1200x1200 32.5 | 32.1,
+	// 1600x1600 50.3 | 49.1, 3840x2160 140.7 | 132.0 | 130.8 | 130.3 | 130.5, 7680x4320 541 | 492.5 | 483.5 | 479.5 | 476.6; round 2's kernels
+	// had 3840x2160 at 214.6 | 222.7 and the rule began at 400k tiles a frame)
+	const bool per_lane = accel == RT_ACCEL_LBVH && sc_sel.skip_count == 0;
+	if (fp.tiles_per_wave <= 0 && lockstep && accel == RT_ACCEL_LBVH && !per_lane && tiles * n_frames >= 400000)
+		tpw = (tiles >= 100000 && tiles * n_frames >= 1600000) ? 4 : (tiles >= 20000 ? 2 : 1);
+	if (fp.tiles_per_wave <= 0 && lockstep && per_lane && tiles >= 400000) tpw = 2;      // (round 2's rule; its runs go along the row)
+	// (the lockstep kernels run a wave's tiles down a column: whole columns of ceil(tile rows / tpw) bands; the per-lane walk's and the
+	// state machine's go along rows)
+	const long long tiles_x = (fp.width + RT_TILE_W - 1) / RT_TILE_W, tiles_y = (fp.local_rows + RT_TILE_H - 1) / RT_TILE_H;
+	const bool column_runs = (lockstep || (count && lockstep_form && accel == RT_ACCEL_LBVH)) && !per_lane;   // (counting launches of the tree kernels: same instance family)
+	const long long waves = column_runs ? tiles_x * ((tiles_y + tpw - 1) / tpw) : (tiles + tpw - 1) / tpw;
 	// Workgroups of ONE wavefront for the tree kernels (no barrier in them; the per-lane walk's LDS stack is laid out for 64 lanes,
 	// RT_STACK_PITCH): a workgroup's resources are released when its last wave ends, and the walks of four tiles differ in
 	// length — measured, 102k triangles, packets, workgroups of 256 | 128 | 64 threads: 800x800 22.1 | 21.2 | 19.6 us/frame

@@ -493,3 +493,25 @@ def test_counting_kernel_follows_the_traversal_in_use():
     for k in ("n_box", "n_plane", "n_point", "n_edge"):
         assert a[k] > 0 and b[k] > 0, k
     assert b["n_box"] != a["n_box"]                   # a wave's walk visits the union of its rays' boxes
+
+
+def test_counting_launches_with_runs_of_tiles_cover_the_frame():
+    """rt_render_stats with rt_scene_set_tiles_per_wave on an LBVH scene: the counting instances of the tree kernels lay their
+    waves out as the frame's kernels do (packets: runs down a column; per lane: along the row) — a launcher that sized the grid
+    for the other form would leave tiles out.  Same frame, same ray counts, whatever the run length."""
+    desc = scenes.spheres(6, 3, 328, 200, depth=2)      # 41 x 25 tiles: neither count is a multiple of the run lengths
+    tr = api.camera_trans(desc.cam_rot)
+    with api.Scene.from_desc(desc) as sc:
+        sc.commit(0, api.ACCEL_LBVH)
+        for mode in (api.TRAVERSAL_PER_LANE, api.TRAVERSAL_PACKET):
+            sc.set_traversal(mode)
+            sc.set_tiles_per_wave(0)
+            want, st0 = sc.render_stats(desc.cam_pos, tr, desc.width, desc.height, desc.depth)
+            for tpw in (2, 3, 7):
+                sc.set_tiles_per_wave(tpw)
+                got, st = sc.render_stats(desc.cam_pos, tr, desc.width, desc.height, desc.depth)
+                assert np.array_equal(_bits(got), _bits(want)), (mode, tpw)
+                a, b = st0.as_dict(), st.as_dict()
+                for k in ("rays_primary", "rays_bounce", "rays_shadow", "px_hit", "px_mirror", "px_lit"):
+                    assert a[k] == b[k], (mode, tpw, k)
+                assert np.array_equal(_bits(sc.render(desc.cam_pos, tr, desc.width, desc.height, desc.depth)), _bits(want)), (mode, tpw)
