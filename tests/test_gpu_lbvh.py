@@ -183,6 +183,29 @@ def test_frame_batches_through_the_tree_equal_single_frames():
         assert not np.array_equal(singles[0], singles[18])
 
 
+def test_long_launches_of_large_frames_equal_single_frames():
+    """The launch shape bench.py times at 3840x2160 — 16 frames of the 102 412-triangle scene in one launch: XCD bands, four tiles
+    per wavefront down a column (launch_render: 129 600 tiles a frame, 2 M in the launch) — against the same poses rendered one
+    frame per launch (one tile per wavefront, no bands): the same bits."""
+    import torch
+    w, h = 3840, 2160
+    desc = scenes.spheres(20, 4, w, h)
+    cams, trs = api.camera_sweep(16, desc.cam_pos, desc.cam_rot)
+    n = w * h * 3
+    with api.Scene.from_desc(desc) as sc:
+        sc.commit(0, api.ACCEL_LBVH)
+        assert sc.traversal(0, trs[0], w, h) == api.TRAVERSAL_PACKET
+        buf = torch.full((16 * n,), -1.0, dtype=torch.float32, device="cuda:0")
+        sc.render_frames_device(0, cams, trs, w, h, desc.depth, api.STRICT, buf.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        one = torch.empty(n, dtype=torch.float32, device="cuda:0")
+        for i in (0, 5, 10, 15):
+            sc.render_device(0, cams[i], trs[i], w, h, desc.depth, api.STRICT, one.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert torch.equal(buf[i * n:(i + 1) * n].view(torch.int32), one.view(torch.int32)), i
+        del buf, one
+
+
 def test_hoisting_limits():
     """Nothing is hoisted from a scene made of large triangles (more than 32 qualify) or from a
     small one where they would be more than a quarter; an all-walls scene still builds."""
