@@ -653,8 +653,11 @@ def run_tile_mode(args, api, torch, dist, rank, world, dev, on_gpu, name):
         del ex
         return float(t[0].item()), kernel_ms, float(t[1].item()), verdict
 
-    # the same frames by ONE GPU in one piece (rank 0, outside the timed region): the N=1 point of this workload
+    # the same frames by ONE GPU in one piece (rank 0, outside the timed region): the N=1 point of this workload.  The other ranks
+    # wait at the barriers: in the one-GPU rehearsal (gloo) they share rank 0's GPU and their counting launches would be timed with it.
     single = None
+    torch.cuda.synchronize()
+    dist.barrier()
     if rank == 0:
         whole = torch.empty(H * W * 3, dtype=torch.float32, device="cuda")
         k = min(8, len(frames))
@@ -668,6 +671,8 @@ def run_tile_mode(args, api, torch, dist, rank, world, dev, on_gpu, name):
         single = {"ms_per_frame": t1 / k * 1e3, "value": sum(w.rays_of[f] for f in frames[:k]) / t1 / 1e6, "frames": k,
                   "note": "whole binary32 frames on rank 0's GPU alone, one frame per launch, frames resident in HBM, no exchange"}
         del whole
+    torch.cuda.synchronize()
+    dist.barrier()
     fmt = args.exchange
     other = "f32" if fmt == "rgba8" else "rgba8"
     wall, kernel_ms, kernel_ms_max, check = leg(fmt, frames, args.warmup, True)
