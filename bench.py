@@ -328,13 +328,13 @@ def stamped(name, workload, key):
     return e if key is None else e.get(key)
 
 
-def issue_use_of(workload, kernel_ms, fpl):
+def issue_use_of(workload, kernel_ms, fpl, share=1.0):
     """Share of the SIMDs' vector issue slots the dominant kernel fills: VALU instructions per launch (rocprofv3 --pmc pass kept under
     profiles/, same sources) priced at the measured cycles per instruction, over SIMDs x the kernel's cycles in THIS run."""
     e = stamped("issue.json", workload, None)
     if not e or not kernel_ms:
         return None
-    k = fpl / float(e.get("frames_per_launch") or fpl)            # (the profiled launch may have held another number of frames)
+    k = fpl / float(e.get("frames_per_launch") or fpl) * share    # (the profiled launch may have held another number of frames; share: the part of a frame this launch renders)
     arith, trans = e["valu_fp32_arith"] * k, e["valu_trans"] * k
     other = e["valu"] * k - arith - trans
     slots = SIMDS * kernel_ms * 1e-3 * CLOCK_GHZ * 1e9
@@ -350,14 +350,22 @@ def issue_use_of(workload, kernel_ms, fpl):
             "profile_round": e.get("round"), "kernel": e.get("kernel")}
 
 
-def roofline_of(flops_per_launch, kernel_ms, fpl, launches, workload):
+def roofline_of(flops_per_launch, kernel_ms, fpl, launches, workload, share=1.0):
+    """share < 1 (row-tile mode): this launch renders that part of ONE frame; profiles/ holds whole-frame launches of the same kernel family,
+    so traffic and the instruction counts behind valu_issue_use are scaled by it (profile_scaled_by says so)."""
     achieved = flops_per_launch / (kernel_ms * 1e-3) / 1e12
     pmc = stamped("traffic.json", workload, "bytes_per_launch")
+    e_fpl = stamped("traffic.json", workload, "frames_per_launch") or stamped("issue.json", workload, "frames_per_launch")
+    scaled = None
+    if share != 1.0:
+        scaled = (fpl / float(e_fpl) if e_fpl else None)
+        scaled = scaled * share if scaled else None
+        pmc = pmc * scaled if (pmc is not None and scaled) else None
     issued = stamped("issued.json", workload, "tflops")
     stale = read_profile_json("issue.json").get(workload) is not None and stamped("issue.json", workload, None) is None
     return {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": pmc, "issued_tflops": issued,
-            "valu_issue_use": issue_use_of(workload, kernel_ms, fpl), "profile_source_hash": source_hash(), "profile_stale": stale,
+            "valu_issue_use": issue_use_of(workload, kernel_ms, fpl, share), "profile_source_hash": source_hash(), "profile_stale": stale, "profile_scaled_by": scaled,
             "kernel_ms": kernel_ms, "flops_per_launch": flops_per_launch, "frames_per_launch": fpl, "launches": launches,
             "note": "FP32 VALU roofline (SURVEY 8d): nothing here is HBM- or MFMA-shaped; algorithmic FLOPs = 14/plane + 6/point + "
                     "17/edge term + 22/box + 32|29|30 per ray, counted in the traversal that is timed; valu_issue_use = share of the SIMDs' "
@@ -696,7 +704,7 @@ def run_tile_mode(args, api, torch, dist, rank, world, dev, on_gpu, name):
                        "output": ("packed 8-bit RGBA pixels (RT_OUT_RGBA8: the GL unorm conversion of the binary32 colour, what the reference's viewer displays)"
                                   if fmt == "rgba8" else "binary32 RGB (the reference's `data`)"),
                        "exchange": "one non-blocking gather of the compact %s shards to rank 0 per frame (%s; shards padded to a common size), two shard buffers per rank" % (fmt, args.backend)},
-            "roofline": roofline_of(flops / args.steps * share, kernel_ms, 1, args.steps, name),
+            "roofline": roofline_of(flops / args.steps * share, kernel_ms, 1, args.steps, name, share),
             "device": device_info(torch, dev),
             "exchange": {"format": fmt, "kernel_ms_rank0": kernel_ms, "kernel_ms_max_over_ranks": kernel_ms_max,
                          "non_render_ms_per_frame": wall / args.steps * 1e3 - kernel_ms_max,
