@@ -56,11 +56,11 @@ WORKLOADS = {
     "room800": (lambda s: s.room(800, 800), "brute",
                 "README room scene (26 triangles, 2 mirror walls, occluder, 1 light) 800x800 depth 1", 64),
     "stock800": (lambda s: s.stock(800, 800), "brute", "unmodified v1 scene (24 triangles, 1 light) 800x800 depth 1", 64),
-    "mirrors4k": (lambda s: s.mirrors(3840, 2160, 16), "brute", "facing mirrors 3840x2160 depth 16", 32),
+    "mirrors4k": (lambda s: s.mirrors(3840, 2160, 16), "brute", "facing mirrors 3840x2160 depth 16", 64),
     "spheres800": (lambda s: s.spheres(20, 4, 800, 800), "lbvh", "20 icospheres x 5120 + room = 102412 triangles, 800x800, LBVH", 64),
-    "spheres4k": (lambda s: s.spheres(20, 4, 3840, 2160), "lbvh", "102412 triangles, 3840x2160, LBVH", 32),
-    "sweep8k": (lambda s: s.room(7680, 4320), "brute", "README room scene 7680x4320, 64-pose camera path", 16),
-    "sweep8k_spheres": (lambda s: s.spheres(20, 4, 7680, 4320), "lbvh", "102412 triangles 7680x4320, 64-pose camera path, LBVH", 16),
+    "spheres4k": (lambda s: s.spheres(20, 4, 3840, 2160), "lbvh", "102412 triangles, 3840x2160, LBVH", 64),
+    "sweep8k": (lambda s: s.room(7680, 4320), "brute", "README room scene 7680x4320, 64-pose camera path", 32),
+    "sweep8k_spheres": (lambda s: s.spheres(20, 4, 7680, 4320), "lbvh", "102412 triangles 7680x4320, 64-pose camera path, LBVH", 32),
 }
 
 SPHERE_SIZES = {"spheres800": (800, 800), "spheres4k": (3840, 2160), "sweep8k_spheres": (7680, 4320)}
@@ -74,7 +74,7 @@ def parse():
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
                     help="default: room800 on one GPU, sweep8k (row tiles + gather) on several")
     ap.add_argument("--tiles-per-wave", type=int, default=0)
-    ap.add_argument("--frames-per-launch", type=int, default=0, help="frames per launch (= per step); 0: the workload's own (64 at 800x800, 32 at 4K, 16 at 8K)")
+    ap.add_argument("--frames-per-launch", type=int, default=0, help="frames per launch (= per step); 0: the workload's own (64 at 800x800 and 4K: 6.4 GB of frames at 4K; 32 at 8K: 12.7 GB)")
     ap.add_argument("--size", type=int, nargs=2, default=None, help="override the workload's frame size (experiments)")
     ap.add_argument("--traversal", default="auto", choices=["auto", "per-lane", "packet"])
     ap.add_argument("--kernel", default="auto", choices=["auto", "state-machine", "lockstep"], help="form of the brute-force render kernel (rt_scene_set_kernel)")
