@@ -1,3 +1,4 @@
+# LBVH tests, then spheres800 / spheres4k with the hoisting of scene-spanning triangles on and off, packets and per lane, interleaved (round 2 study)
 set -e
 mkdir -p gpurun_out
 timeout -k 10 400 python -u -m pytest tests/test_gpu_lbvh.py tests/test_gpu_packet.py -x -q --timeout 120 --timeout-method thread > gpurun_out/hoist_tests.log 2>&1 || { tail -30 gpurun_out/hoist_tests.log; exit 1; }

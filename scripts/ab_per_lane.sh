@@ -1,3 +1,4 @@
+# A/B of two library builds on the kernels a change to the tile loop touches besides the packet kernel: the shard instance (multi-GPU ranks) and the per-lane walk
 cd /root/repo
 for lib in build/librt355_row.so raytracing_amd/librt355.so; do
   echo "== $lib"

@@ -1,3 +1,4 @@
+"""102k triangles at 640x360, depth 4: per-lane == packets == brute force, bit for bit (quick check on a GPU box)."""
 import sys, os
 sys.path.insert(0, os.getcwd())
 import numpy as np

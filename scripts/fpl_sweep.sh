@@ -1,3 +1,4 @@
+# us/frame against frames per launch and tiles per wave at 3840x2160 and 7680x4320 (the launch shape)
 cd /root/repo
 run() { timeout -k 10 150 python3 bench.py --workload $1 --steps 8 --warmup 3 --no-configs --no-cpu $2 > gpurun_out/fpl.json 2>gpurun_out/fpl_err.log || exit 1
   python3 -c "

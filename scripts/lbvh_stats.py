@@ -1,3 +1,4 @@
+"""Commit and re-commit wall time of the 102k-triangle scene and the work counters of one frame through the tree, per ray."""
 import sys, os, time
 sys.path.insert(0, os.getcwd())
 from raytracing_amd import api, scenes

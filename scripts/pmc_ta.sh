@@ -1,3 +1,4 @@
+# texture-addresser / vector L1 busy and stall counters of spheres800's render kernel, one rocprofv3 --pmc pass each -> gpurun_out/pmc3/
 export TMPDIR=/tmp
 o=gpurun_out/pmc3; rm -rf $o; mkdir -p $o
 rocprofv3 -L 2>/dev/null | grep -E "^\s*(Name|name)?\s*:?\s*(TA_|TCP_)" | head -60 > $o/list.txt; wc -l $o/list.txt

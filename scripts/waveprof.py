@@ -1,3 +1,4 @@
+"""Per-wave stage counters of a render (RT_PROFILE build, RT355_LIB=build/librt355_prof.so): usage waveprof.py <scene> [w h]."""
 import sys, os
 sys.path.insert(0, os.getcwd())
 from raytracing_amd import api, scenes
