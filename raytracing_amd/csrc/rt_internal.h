@@ -130,6 +130,7 @@ struct FrameParams {
 	// the frame number evens out bands of different cost over the frames of the launch.
 	unsigned int band_blocks;
 	long long frame_stride;         // 4-byte elements between consecutive frames in `out`
+	unsigned long long origin_inside;   // bit f: frame f's camera lies inside the scene box (set by the launcher; rt_kernels.hip exit_bound_is_idle)
 	int width, height;      // Source.cpp:887-888
 	int max_bounces;        // Source.cpp:567
 	int tile_rows, tile_first, tile_stride;

@@ -964,8 +964,24 @@ __device__ __forceinline__ void pose_from_kernel_args(const FrameParams& fp_arg,
 	for (int k = 0; k < 12; k++) m[k] = fp_arg.pose[frame][k];
 #endif
 }
+// The exit bound of a trace (where the ray leaves the padded scene box: no hit lies beyond) only ever skips work — and it has
+// none to skip for a ray that STARTS inside the box: everything the scene holds lies before the exit.  A bounce ray starts at a hit
+// point, i.e. on a triangle (the box is padded by 1e-3 of the scene, orders of magnitude above the rounding of o + t*d); a primary
+// ray starts at the camera, and the launcher says per frame whether that is inside (FrameParams::origin_inside, wave-uniform).
+// Those traces search up to the reference's own 1e9 (Source.cpp:278) and save the slab arithmetic: 13 vector instructions.
+#ifndef RT_SKIP_IDLE_EXIT
+#define RT_SKIP_IDLE_EXIT 1
+#endif
+template <int KIND>
+__device__ __forceinline__ bool exit_bound_is_idle(bool from_inside) {
+#if RT_SKIP_IDLE_EXIT
+	if constexpr (KIND == RAY_BOUNCE) return true;
+	else if constexpr (KIND == RAY_PRIMARY) return from_inside;
+#endif
+	return false;
+}
 template <int ACCEL, int KIND>
-__device__ __forceinline__ Hit trace_brute(const DevScene& sc_arg, const float* lds_num0, vec3 o, vec3 d, int skip, bool live, float dist, WaveProf& wp) {
+__device__ __forceinline__ Hit trace_brute(const DevScene& sc_arg, const float* lds_num0, vec3 o, vec3 d, int skip, bool live, float dist, WaveProf& wp, bool from_inside = false) {
 	static_assert(ACCEL == 0 || ACCEL == 1, "brute force only");
 	const DevScene sc = scene_from_kernel_args(sc_arg);
 	// (the comments of trace<> above apply word for word: clamped direction, exit bound, far_guard, octant)
@@ -973,10 +989,13 @@ __device__ __forceinline__ Hit trace_brute(const DevScene& sc_arg, const float* 
 	const bool near = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) < sc.far_guard;
 	vec3 inv = make3(__builtin_amdgcn_rcpf(ds.x), __builtin_amdgcn_rcpf(ds.y), __builtin_amdgcn_rcpf(ds.z));
 	vec3 oi = make3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
-	const float ex = fminf(fminf(fmaxf(__builtin_fmaf(sc.bb_lo[0], inv.x, oi.x), __builtin_fmaf(sc.bb_hi[0], inv.x, oi.x)),
-	                             fmaxf(__builtin_fmaf(sc.bb_lo[1], inv.y, oi.y), __builtin_fmaf(sc.bb_hi[1], inv.y, oi.y))),
-	                       fmaxf(__builtin_fmaf(sc.bb_lo[2], inv.z, oi.z), __builtin_fmaf(sc.bb_hi[2], inv.z, oi.z)));
-	float lim = fminf(ex + fabsf(ex) * 1e-4f, 1e9f);                     // 1e9: Source.cpp:278
+	float lim = 1e9f;                                                    // 1e9: Source.cpp:278
+	if (!exit_bound_is_idle<KIND>(from_inside)) {
+		const float ex = fminf(fminf(fmaxf(__builtin_fmaf(sc.bb_lo[0], inv.x, oi.x), __builtin_fmaf(sc.bb_hi[0], inv.x, oi.x)),
+		                             fmaxf(__builtin_fmaf(sc.bb_lo[1], inv.y, oi.y), __builtin_fmaf(sc.bb_hi[1], inv.y, oi.y))),
+		                       fmaxf(__builtin_fmaf(sc.bb_lo[2], inv.z, oi.z), __builtin_fmaf(sc.bb_hi[2], inv.z, oi.z)));
+		lim = fminf(ex + fabsf(ex) * 1e-4f, 1e9f);
+	}
 	const bool some_far = __builtin_amdgcn_ballot_w64(live && !near) != 0ull;      // (rays from beyond far_guard: rare, wave-uniform branch)
 	if (some_far && !near) { lim = 1e9f; inv = make3(0.f, 0.f, 0.f); oi = make3(0.f, 0.f, 0.f); }
 	// a shadow ray's limit is the first float > dist (Source.cpp:476); the exit bound could only repeat what that already says
@@ -999,16 +1018,20 @@ __device__ __forceinline__ Hit trace_brute(const DevScene& sc_arg, const float* 
 // castRay over the LBVH by packets for ONE kind of ray (lockstep kernel): one walk per direction octant
 // present among the live lanes (one pass for almost every wave).  Same set-up as trace<3>.
 template <int KIND, bool COUNT>
-__device__ __forceinline__ Hit trace_packet(const DevScene& sc_arg, vec3 o, vec3 d, int skip, bool live, float dist, LaneCounters& lc, WaveProf& wp, HoistCtx hc = HoistCtx()) {
+__device__ __forceinline__ Hit trace_packet(const DevScene& sc_arg, vec3 o, vec3 d, int skip, bool live, float dist, LaneCounters& lc, WaveProf& wp, HoistCtx hc = HoistCtx(),
+                                             bool from_inside = false) {
 	const DevScene sc = scene_from_kernel_args(sc_arg);
 	const vec3 ds = make3(fabsf(d.x) < 1e-30f ? 1e-30f : d.x, fabsf(d.y) < 1e-30f ? 1e-30f : d.y, fabsf(d.z) < 1e-30f ? 1e-30f : d.z);
 	const bool near = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) < sc.far_guard;   // false for NaN too
 	vec3 inv = make3(__builtin_amdgcn_rcpf(ds.x), __builtin_amdgcn_rcpf(ds.y), __builtin_amdgcn_rcpf(ds.z));
 	vec3 oi = make3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
-	const float ex = fminf(fminf(fmaxf(__builtin_fmaf(sc.bb_lo[0], inv.x, oi.x), __builtin_fmaf(sc.bb_hi[0], inv.x, oi.x)),
-	                             fmaxf(__builtin_fmaf(sc.bb_lo[1], inv.y, oi.y), __builtin_fmaf(sc.bb_hi[1], inv.y, oi.y))),
-	                       fmaxf(__builtin_fmaf(sc.bb_lo[2], inv.z, oi.z), __builtin_fmaf(sc.bb_hi[2], inv.z, oi.z)));
-	float lim = fminf(ex + fabsf(ex) * 1e-4f, 1e9f);
+	float lim = 1e9f;
+	if (!exit_bound_is_idle<KIND>(from_inside)) {
+		const float ex = fminf(fminf(fmaxf(__builtin_fmaf(sc.bb_lo[0], inv.x, oi.x), __builtin_fmaf(sc.bb_hi[0], inv.x, oi.x)),
+		                             fmaxf(__builtin_fmaf(sc.bb_lo[1], inv.y, oi.y), __builtin_fmaf(sc.bb_hi[1], inv.y, oi.y))),
+		                       fmaxf(__builtin_fmaf(sc.bb_lo[2], inv.z, oi.z), __builtin_fmaf(sc.bb_hi[2], inv.z, oi.z)));
+		lim = fminf(ex + fabsf(ex) * 1e-4f, 1e9f);
+	}
 	if (__builtin_amdgcn_ballot_w64(live && !near) != 0ull) {          // rays from beyond far_guard: every box tests as hit for them
 		if (!near) { lim = 1e9f; inv = make3(0.f, 0.f, 0.f); oi = make3(0.f, 0.f, 0.f); }
 	}
@@ -1034,12 +1057,12 @@ __device__ __forceinline__ Hit trace_packet(const DevScene& sc_arg, vec3 o, vec3
 // COUNT (tree kernels only): the work counters of SURVEY 8d, as the state-machine kernel keeps them
 template <int ACCEL, int KIND, bool COUNT>
 __device__ __forceinline__ Hit trace_kind(const DevScene& sc, const float* lds_num0, vec3 o, vec3 d, int skip, bool live, float dist, LaneCounters& lc, WaveProf& wp,
-                                          HoistCtx hc = HoistCtx()) {
-	if constexpr (ACCEL == 3) return trace_packet<KIND, COUNT>(sc, o, d, skip, live, dist, lc, wp, hc);
+                                          HoistCtx hc = HoistCtx(), bool from_inside = false) {
+	if constexpr (ACCEL == 3) return trace_packet<KIND, COUNT>(sc, o, d, skip, live, dist, lc, wp, hc, from_inside);
 	else if constexpr (ACCEL == 2) return cast_ray_lbvh<COUNT>(sc, (int*)lds_num0, o, d, skip, live, KIND == RAY_SHADOW, dist, lc, wp, hc);   // (lds_num0: the workgroup's LDS, here the stacks)
 	else {
 		static_assert(!COUNT, "the brute-force counters follow the reference-order loop of the state-machine kernel");
-		return trace_brute<ACCEL, KIND>(sc, lds_num0, o, d, skip, live, dist, wp);
+		return trace_brute<ACCEL, KIND>(sc, lds_num0, o, d, skip, live, dist, wp, from_inside);
 	}
 }
 
@@ -1434,7 +1457,7 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 			}
 		}
 		if (vis_list_n >= 0) h = trace_primary_vis<ACCEL == 3 ? 3 : 2, COUNT>(sc, fp, frame, vis_list_n, (long long)ly * fp_top.width + x, cam_t, d, inside, lc, wp, hc);
-		else h = trace_kind<ACCEL, RAY_PRIMARY, COUNT>(sc, s_num0, cam_t, d, -1, inside, 0.f, lc, wp, hc);
+		else h = trace_kind<ACCEL, RAY_PRIMARY, COUNT>(sc, s_num0, cam_t, d, -1, inside, 0.f, lc, wp, hc, ((fp_top.origin_inside >> frame) & 1ull) != 0ull);
 		const bool hit = inside && h.idx >= 0;
 		if constexpr (COUNT) { ctr[CTR_PRIMARY] += inside; ctr[CTR_PXHIT] += hit; }
 		float4 A = make_float4(0.f, 0.f, 0.f, 0.f);                          // colour, shininess of the triangle to be lit
@@ -1714,6 +1737,12 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 	const long long blocks = (waves + wpb - 1) / wpb;
 	if (blocks * n_frames > 0x7fffffffLL) { set_error("rt_render: frame too large (%lld workgroups)", blocks * n_frames); return RT_ERR_LIMIT; }
 	fp.n_frames = n_frames;
+	fp.origin_inside = 0ull;                // which frames' cameras lie inside the (padded) scene box: their primary rays need no exit bound
+	for (int f = 0; f < n_frames && f < 64; f++) {
+		bool in = true;
+		for (int k = 0; k < 3; k++) in = in && fp.pose[f][k] > sc.bb_lo[k] && fp.pose[f][k] < sc.bb_hi[k];
+		if (in) fp.origin_inside |= 1ull << f;
+	}
 	fp.blocks_per_frame = (unsigned int)blocks;
 	dim3 grid((unsigned)(blocks * n_frames)), block((unsigned)threads);
 	// XCD-aware workgroup order for multi-frame LBVH launches (rt_internal.h FrameParams::band_blocks).
