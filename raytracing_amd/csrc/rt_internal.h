@@ -99,6 +99,7 @@ struct DevScene {
 	// scene bounding box, padded (host: rt_api.cpp scene_box); +-inf when the scene has none
 	float bb_lo[3], bb_hi[3];
 	float far_guard;        // |origin| beyond this: the box tests are switched off for the ray
+	int box_within_guard;   // 1: the whole scene box lies within far_guard — a ray that starts inside the box needs no check (rt_kernels.hip dev_scene)
 	float packet_scale;     // scene diagonal / mean triangle box diagonal (launcher: is an 8x8 tile of rays coherent?)
 	int traversal;          // rt_scene_set_traversal: RT_TRAVERSAL_AUTO | _PER_LANE | _PACKET (host side only)
 	int kernel_kind;        // rt_scene_set_kernel (host side only)

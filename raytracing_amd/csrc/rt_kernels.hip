@@ -972,6 +972,7 @@ __device__ __forceinline__ void pose_from_kernel_args(const FrameParams& fp_arg,
 #ifndef RT_SKIP_IDLE_EXIT
 #define RT_SKIP_IDLE_EXIT 1
 #endif
+
 template <int KIND>
 __device__ __forceinline__ bool exit_bound_is_idle(bool from_inside) {
 #if RT_SKIP_IDLE_EXIT
@@ -989,7 +990,7 @@ __device__ __forceinline__ Hit trace_brute(const DevScene& sc_arg, const float* 
 	const bool near = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) < sc.far_guard;
 	vec3 inv = make3(__builtin_amdgcn_rcpf(ds.x), __builtin_amdgcn_rcpf(ds.y), __builtin_amdgcn_rcpf(ds.z));
 	vec3 oi = make3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
-	float lim = 1e9f;                                                    // 1e9: Source.cpp:278
+	float lim = 1e9f;                                                    // 1e9: Source.cpp:278 (the box's diagonal as a free limit for bounce rays: no gain, measured)
 	if (!exit_bound_is_idle<KIND>(from_inside)) {
 		const float ex = fminf(fminf(fmaxf(__builtin_fmaf(sc.bb_lo[0], inv.x, oi.x), __builtin_fmaf(sc.bb_hi[0], inv.x, oi.x)),
 		                             fmaxf(__builtin_fmaf(sc.bb_lo[1], inv.y, oi.y), __builtin_fmaf(sc.bb_hi[1], inv.y, oi.y))),
@@ -1022,7 +1023,11 @@ __device__ __forceinline__ Hit trace_packet(const DevScene& sc_arg, vec3 o, vec3
                                              bool from_inside = false) {
 	const DevScene sc = scene_from_kernel_args(sc_arg);
 	const vec3 ds = make3(fabsf(d.x) < 1e-30f ? 1e-30f : d.x, fabsf(d.y) < 1e-30f ? 1e-30f : d.y, fabsf(d.z) < 1e-30f ? 1e-30f : d.z);
-	const bool near = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) < sc.far_guard;   // false for NaN too
+	// An origin inside a scene box that lies within far_guard is within far_guard — hit points always, the camera when the launcher
+	// says so: no check then.  (Packets only: 3840x2160 128.05 -> 127.15 us/frame, 800x800 18.95 -> 18.90; the brute-force traces
+	// came out 0.3 % slower with it and keep the check.)
+	const bool near_known = RT_SKIP_IDLE_EXIT && sc.box_within_guard != 0 && (KIND != RAY_PRIMARY || from_inside);
+	const bool near = near_known || fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) < sc.far_guard;   // false for NaN too
 	vec3 inv = make3(__builtin_amdgcn_rcpf(ds.x), __builtin_amdgcn_rcpf(ds.y), __builtin_amdgcn_rcpf(ds.z));
 	vec3 oi = make3(-(o.x * inv.x), -(o.y * inv.y), -(o.z * inv.z));
 	float lim = 1e9f;
@@ -1032,7 +1037,7 @@ __device__ __forceinline__ Hit trace_packet(const DevScene& sc_arg, vec3 o, vec3
 		                       fmaxf(__builtin_fmaf(sc.bb_lo[2], inv.z, oi.z), __builtin_fmaf(sc.bb_hi[2], inv.z, oi.z)));
 		lim = fminf(ex + fabsf(ex) * 1e-4f, 1e9f);
 	}
-	if (__builtin_amdgcn_ballot_w64(live && !near) != 0ull) {          // rays from beyond far_guard: every box tests as hit for them
+	if (!near_known && __builtin_amdgcn_ballot_w64(live && !near) != 0ull) {          // rays from beyond far_guard: every box tests as hit for them
 		if (!near) { lim = 1e9f; inv = make3(0.f, 0.f, 0.f); oi = make3(0.f, 0.f, 0.f); }
 	}
 	if constexpr (KIND == RAY_SHADOW) lim = __uint_as_float(__float_as_uint(dist) + 1u);   // (no exit bound: see trace_brute)
@@ -1059,7 +1064,7 @@ template <int ACCEL, int KIND, bool COUNT>
 __device__ __forceinline__ Hit trace_kind(const DevScene& sc, const float* lds_num0, vec3 o, vec3 d, int skip, bool live, float dist, LaneCounters& lc, WaveProf& wp,
                                           HoistCtx hc = HoistCtx(), bool from_inside = false) {
 	if constexpr (ACCEL == 3) return trace_packet<KIND, COUNT>(sc, o, d, skip, live, dist, lc, wp, hc, from_inside);
-	else if constexpr (ACCEL == 2) return cast_ray_lbvh<COUNT>(sc, (int*)lds_num0, o, d, skip, live, KIND == RAY_SHADOW, dist, lc, wp, hc);   // (lds_num0: the workgroup's LDS, here the stacks)
+	else if constexpr (ACCEL == 2) return cast_ray_lbvh<COUNT>(sc, (int*)lds_num0, o, d, skip, live, KIND == RAY_SHADOW, dist, lc, wp, hc, exit_bound_is_idle<KIND>(from_inside));   // (lds_num0: the workgroup's LDS, here the stacks)
 	else {
 		static_assert(!COUNT, "the brute-force counters follow the reference-order loop of the state-machine kernel");
 		return trace_brute<ACCEL, KIND>(sc, lds_num0, o, d, skip, live, dist, wp, from_inside);
@@ -1611,6 +1616,8 @@ DevScene dev_scene(const rt_scene* s, const DeviceState& d) {
 	sc.hoist = (const float4*)d.hoist;
 	sc.hoist_count = d.hoist_count;
 	sc.far_guard = d.far_guard;
+	sc.box_within_guard = 1;
+	for (int k = 0; k < 3; k++) if (!(fabsf(d.bb_lo[k]) < d.far_guard && fabsf(d.bb_hi[k]) < d.far_guard)) sc.box_within_guard = 0;
 	sc.packet_scale = d.packet_scale;
 	sc.traversal = s->traversal;
 	sc.kernel_kind = s->kernel_kind;
@@ -1640,7 +1647,7 @@ static bool use_packets_cols(const DevScene& sc, const float col0[3], const floa
 	const float du = sqrtf(col0[0] * col0[0] + col0[1] * col0[1] + col0[2] * col0[2]) / (float)(width > 0 ? width : 1);
 	const float dv = sqrtf(col1[0] * col1[0] + col1[1] * col1[1] + col1[2] * col1[2]) / (float)(height > 0 ? height : 1);
 	const float footprint = 8.0f * 0.5f * (du + dv) * sc.packet_scale;
-	return footprint < 6.0f;
+	return footprint < 5.0f;
 }
 
 static int pick_tiles_per_wave(int accel, long long tiles) {
@@ -1695,7 +1702,9 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 	// 18.4 | 10.9, 500 (7.4) 20.4 | 15.5, 600 (6.1) 21.0 | 18.7, 800 (4.6) 26.4 | 29.0, 1000 (3.7) 34.3 | 41.6, 1200 (3.1) 44.4 | 55.9,
 	// 1600 (2.3) 67.9 | 90.5, 2400 (1.5) 127.5 | 183.5, 3840x2160 (1.3) 172.1 | 244.7: packets below a footprint of 5.5.  Re-measured
 	// with 64 frames per launch and workgroups of one wavefront: 300 11.4 | 5.2, 400 11.3 | 7.5, 500 11.9 | 10.3, 600 (6.1) 13.5 | 13.3,
-	// 700 (5.3) 16.0 | 17.2, 800 18.9 | 21.3, 1000 24.9 | 30.3: packets below 6.
+	// 700 (5.3) 16.0 | 17.2, 800 18.9 | 21.3, 1000 24.9 | 30.3: packets below 6.  And once more after the per-lane walk lost its exit bound
+	// (and with it its spilled registers): 500 11.9 | 9.65, 600 13.5 | 12.4, 700 (5.3) 16.2 | 16.0, 800 (4.6) 19.0 | 20.1, 900 22.0 | 24.0,
+	// 1000 25.0 | 28.5: packets below 5.
 	DevScene sc_sel = sc;
 	if (accel == RT_ACCEL_LBVH) {
 		bool packets = use_packets_cols(sc, fp.pose[0] + 3, fp.pose[0] + 6, fp.width, fp.height);

@@ -47,7 +47,7 @@ __device__ __forceinline__ void cswap(float& ka, int& ra, float& kb, int& rb) {
 
 template <bool COUNT>
 __device__ __forceinline__ Hit cast_ray_lbvh(const DevScene& sc, int* lds_stack, vec3 o, vec3 d, int skip, bool live,
-                                             bool shadow, float dist, LaneCounters& lc, WaveProf& wp, HoistCtx hc = HoistCtx()) {
+                                             bool shadow, float dist, LaneCounters& lc, WaveProf& wp, HoistCtx hc = HoistCtx(), bool idle_exit = false) {
 	RT_PROF(wp, WP_TRACE);
 	Hit h;
 	h.t = 1e9f;                                                          // Source.cpp:278
@@ -61,10 +61,14 @@ __device__ __forceinline__ Hit cast_ray_lbvh(const DevScene& sc, int* lds_stack,
 		s.oi = make3(-(o.x * s.inv.x), -(o.y * s.inv.y), -(o.z * s.inv.z));
 	}
 	// where the ray leaves the padded scene box: no hit lies beyond (same arithmetic as the slabs)
-	const float ex = fminf(fminf(fmaxf(__builtin_fmaf(sc.bb_lo[0], s.inv.x, s.oi.x), __builtin_fmaf(sc.bb_hi[0], s.inv.x, s.oi.x)),
-	                             fmaxf(__builtin_fmaf(sc.bb_lo[1], s.inv.y, s.oi.y), __builtin_fmaf(sc.bb_hi[1], s.inv.y, s.oi.y))),
-	                       fmaxf(__builtin_fmaf(sc.bb_lo[2], s.inv.z, s.oi.z), __builtin_fmaf(sc.bb_hi[2], s.inv.z, s.oi.z)));
-	float lim = cull ? fminf(ex + fabsf(ex) * 1e-4f, 1e9f) : 1e9f;
+	// (idle_exit, wave-uniform: the rays start inside the box, where the bound has nothing to skip — rt_kernels.hip exit_bound_is_idle)
+	float lim = 1e9f;
+	if (!idle_exit) {
+		const float ex = fminf(fminf(fmaxf(__builtin_fmaf(sc.bb_lo[0], s.inv.x, s.oi.x), __builtin_fmaf(sc.bb_hi[0], s.inv.x, s.oi.x)),
+		                             fmaxf(__builtin_fmaf(sc.bb_lo[1], s.inv.y, s.oi.y), __builtin_fmaf(sc.bb_hi[1], s.inv.y, s.oi.y))),
+		                       fmaxf(__builtin_fmaf(sc.bb_lo[2], s.inv.z, s.oi.z), __builtin_fmaf(sc.bb_hi[2], s.inv.z, s.oi.z)));
+		if (cull) lim = fminf(ex + fabsf(ex) * 1e-4f, 1e9f);
+	}
 	if (shadow) lim = __uint_as_float(__float_as_uint(dist) + 1u);                      // Source.cpp:476 (the exit bound has nothing to add: the lockstep kernel drops it)
 	lim = fminf(lim, 1e9f);
 	float lim_hi = lim + fabsf(lim) * RT_PREFILTER_REL;

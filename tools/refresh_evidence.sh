@@ -4,9 +4,9 @@
 # and keeps its line as profiles/<tag>_bench.json.  Two gpurun calls, ~4 GPU-minutes.
 tag=${1:-r03}
 cd "$(dirname "$0")/.."
-/usr/local/graft/bin/gpurun --timeout 1200 -- "bash tools/profile.sh $tag \"room800 spheres800 spheres4k mirrors4k sweep8k sweep8k_spheres stock800\" > gpurun_out/prof_$tag.log 2>&1; echo profile rc=\$?" 2>&1 | grep -E "rc=|status" || exit 1
+/usr/local/graft/bin/gpurun --timeout 1200 -- "bash tools/profile.sh $tag \"room800 spheres800 spheres4k mirrors4k sweep8k sweep8k_spheres stock800\" > gpurun_out/prof_$tag.log 2>&1; echo profile rc=\$?" 2>&1 | tee /dev/stderr | grep -q "profile rc=0" || { echo "profile step did not run to the end (a transient refusal: wait and run again)"; exit 1; }
 python tools/keep_profiles.py $tag > /dev/null || exit 1
-/usr/local/graft/bin/gpurun --timeout 900 -- "timeout -k 10 800 python bench.py > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err; echo bench rc=\$?" 2>&1 | grep -E "rc=|status" || exit 1
+/usr/local/graft/bin/gpurun --timeout 900 -- "timeout -k 10 800 python bench.py > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err; echo bench rc=\$?" 2>&1 | tee /dev/stderr | grep -q "bench rc=0" || { echo "bench step did not run to the end (a transient refusal: wait and run again)"; exit 1; }
 cp gpurun_out/bench_$tag.json profiles/${tag}_bench.json
 fp=$(python raytracing_amd/srchash.py)
 sed -i "s/The entries here are fingerprint \`[0-9a-f]*\`/The entries here are fingerprint \`$fp\`/" profiles/README.md
