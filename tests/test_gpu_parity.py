@@ -473,3 +473,30 @@ def test_many_random_soups_vs_oracle(oracle):
             if not np.array_equal(_bits(got), _bits(want)):
                 bad.append((seed, accel, int((_bits(got) != _bits(want)).any(axis=2).sum())))
     assert not bad, bad
+
+
+def test_cameras_inside_and_outside_the_scene_box_in_one_launch(oracle):
+    """launch_render marks, per frame, the cameras that lie inside the scene box: their primary rays (and every bounce ray) search
+    without the exit bound (rt_kernels.hip exit_bound_is_idle).  A camera path that starts inside the room and ends far outside
+    it, rendered in ONE launch by brute force and through the tree (both walks): every frame equals the oracle's frame for its pose."""
+    import torch
+    base = scenes.room(96, 64)
+    n = 12
+    poses = [(base.cam_pos[0] - 4.0 * k, base.cam_pos[1] + 0.7 * k, base.cam_pos[2] + 1.3 * k) for k in range(n)]   # leaves the box after a few steps
+    rot = base.cam_rot
+    tr = np.tile(api.camera_trans(rot), (n, 1))
+    cams = np.asarray(poses, np.float32)
+    want = [oracle.render_desc(base.with_camera(p, rot), threads=8) for p in poses]
+    elems = base.width * base.height * 3
+    with api.Scene.from_desc(base) as sc:
+        for accel, trav in ((api.ACCEL_BRUTE, api.TRAVERSAL_AUTO), (api.ACCEL_LBVH, api.TRAVERSAL_PER_LANE), (api.ACCEL_LBVH, api.TRAVERSAL_PACKET)):
+            sc.commit(0, accel)
+            sc.set_traversal(trav)
+            buf = torch.full((n * elems,), -1.0, dtype=torch.float32, device="cuda:0")
+            sc.render_frames_device(0, cams, tr, base.width, base.height, base.depth, api.STRICT, buf.data_ptr(), elems, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            got = buf.cpu().numpy().reshape(n, base.height, base.width, 3)
+            for k in range(n):
+                assert np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32)), (accel, trav, k)
+    lit = [int((w.sum(axis=2) > 0).sum()) for w in want]
+    assert lit[0] > 0 and lit[-1] != lit[0]          # (the path really changes what is seen)
