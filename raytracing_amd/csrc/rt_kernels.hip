@@ -450,7 +450,6 @@ template <bool COUNT>
 __device__ __forceinline__ void hoisted_by_mask(const DevScene& sc, unsigned int hm, vec3 o, vec3 d, int skip, bool first_only,
                                                 Hit& h, float& lim, float& lim_hi, LaneCounters& lc, WaveProf& wp) {
 	const c4ptr hrec = c4ptr_of(sc.hoist);
-	const c4ptr hbox = hrec.offset_floats((unsigned int)sc.hoist_count * (RT_AOS_F4 * 4u));     // (octant 0's boxes: the second float4 of record j ends with the triangle's index)
 	const float eps_lo = RT_EPS_BELOW * (1.0f - RT_PREFILTER_REL);
 	unsigned int left = lim >= 0.0f ? hm : 0u;
 	for (;;) {
@@ -462,11 +461,16 @@ __device__ __forceinline__ void hoisted_by_mask(const DevScene& sc, unsigned int
 			const int j = __builtin_ctz(m);
 			m &= m - 1u;
 			if (j >= sc.hoist_count) break;
-			const int i = __float_as_int(hbox[(unsigned int)j * 2u + 1u].w);
+			// (the triangle's index comes with the record's first 32 bytes — rt_lbvh.hip k_hoist — which the test needs anyway: a separate
+			// load of it was one more round trip through the scalar cache in front of every test)
+			const c4ptr R = hrec.offset_floats((unsigned int)j * (RT_AOS_F4 * 4u));
+			float4 N4, P14;
+			R.pair(0, N4, P14);
+			const int i = __float_as_int(P14.w);
 			const bool want = lim >= 0.0f && ((hm >> j) & 1u) != 0u && i != skip;
 			if (__builtin_amdgcn_ballot_w64(want) == 0ull) continue;
 			RT_PROF(wp, WP_INBOX);
-			packet_leaf<COUNT>(hrec.offset_floats((unsigned int)j * (RT_AOS_F4 * 4u)), i, o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp);
+			packet_leaf<COUNT>(R, i, o, d, skip, first_only, eps_lo, h, lim, lim_hi, lc, wp);
 		}
 	}
 }

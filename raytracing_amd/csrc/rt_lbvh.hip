@@ -373,6 +373,7 @@ __global__ void __launch_bounds__(64) k_hoist(const float4* __restrict__ planes,
 		i = idx[j];
 		keys[i] = (1ull << 63) | (u64)(unsigned int)i;
 		aos_record(planes, stride, i, out + (size_t)j * RT_AOS_F4);
+		out[(size_t)j * RT_AOS_F4 + 1].w = __int_as_float(i);      // (a hoisted record carries its triangle's index where P1's plane has a colour: hoisted_by_mask reads it with N and P1)
 		float lo[3], hi[3];
 		tri_box_padded(planes, stride, i, pad, lo, hi);
 		for (int a = 0; a < 3; a++) { s_lo[j][a] = lo[a]; s_hi[j][a] = hi[a]; }
