@@ -1,3 +1,4 @@
+# A/B of two library builds on what the per-lane walk serves: 400x400 and 800x800 per lane, 3840x2160 by packets (control), lone 800x800 frames
 cd /root/repo
 for i in 1 2; do
 for lib in build/librt355_prev.so raytracing_amd/librt355.so; do
