@@ -1367,7 +1367,7 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 #endif
 // PLAIN: a whole frame (no row tiles) whose u, v are division-free — the launcher's common case, compiled without the
 // row mapping and the slow forms of Source.cpp:534-535, whose wave-uniform conditions otherwise sit in spilled SGPRs
-// and are re-read for every tile.  Instantiated for packets and for brute force with the numerator table (launch_render).
+// and are re-read for every tile.  Instantiated for the tree kernels and for brute force with the numerator table (launch_render).
 // COUNT (tree kernels): the work counters of rt_render_stats, counted in the very traversal a frame gets.
 template <int ACCEL, bool PLAIN, bool COUNT = false>
 __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL == 3 ? RT_MIN_WAVES_PACKET : RT_MIN_WAVES)) render_lockstep_kernel(DevScene sc, FrameParams fp, int tiles_per_wave) {
@@ -1790,7 +1790,8 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 	// render_lockstep_kernel<ACCEL, PLAIN>: measured +1.5 % for packets; the brute-force and per-lane instances got 2-3 % SLOWER with it in
 	// round 2 (register allocation).  Measured again at the end of round 3 for brute force (scenes with the numerator table), general |
 	// plain: room 800x800 10.19 | 10.10 us/frame, stock 7.14 | 7.07, mirrors 3840x2160 204.5 | 204.0, room 7680x4320 482.4 | 478.8 —
-	// so ACCEL 0 has the plain instance too; the per-lane walk and forced brute force on larger scenes keep the general form.
+	// so ACCEL 0 has the plain instance too, and so has the per-lane walk (400x400 6.95 | 6.91, 800x800 19.83 | 19.68, a lone 800x800 frame
+	// 119.1 | 118.4); forced brute force on larger scenes keeps the general form.
 	const bool plain = fp.uv_fast && fp.tile_stride == 1 && fp.tile_first == 0;
 	if (accel == RT_ACCEL_LBVH) {
 		const size_t lds = (size_t)RT_STACK_LDS * RT_STACK_PITCH * sizeof(int);   // [entry][lane]
@@ -1803,6 +1804,7 @@ int launch_render(const DevScene& sc, const FrameParams& fp_in, int accel, int r
 		else if (sc_sel.skip_count > 0 && lockstep && plain) hipLaunchKernelGGL((render_lockstep_kernel<3, true>), grid, block, lds_h, stream, sc_sel, fp, tpw);
 		else if (sc_sel.skip_count > 0 && lockstep) hipLaunchKernelGGL((render_lockstep_kernel<3, false>), grid, block, lds_h, stream, sc_sel, fp, tpw);
 		else if (sc_sel.skip_count > 0) hipLaunchKernelGGL((render_kernel<3, false>), grid, block, 0, stream, sc_sel, fp, tpw);
+		else if (lockstep && plain) hipLaunchKernelGGL((render_lockstep_kernel<2, true>), grid, block, lds + lds_h, stream, sc_sel, fp, tpw);
 		else if (lockstep) hipLaunchKernelGGL((render_lockstep_kernel<2, false>), grid, block, lds + lds_h, stream, sc_sel, fp, tpw);
 		else hipLaunchKernelGGL((render_kernel<2, false>), grid, block, lds, stream, sc_sel, fp, tpw);
 	} else if (sc.n_tris <= RT_LDS_MAX_TRIS) {
