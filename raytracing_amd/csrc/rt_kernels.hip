@@ -1349,6 +1349,17 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 	}
 }
 
+// reflect(I, face_normal(I, n)) (Source.cpp:443-453, glm reflect: I - (N * dot(N, I)) * 2) with ONE dot product: N is n or -n, and
+// dot(-n, I) is exactly -dot(n, I) — every product and both sums change sign and nothing else (round-to-nearest is symmetric), and
+// dot(n, I) is dot(I, n) product by product — so the second dot product of the pair is the first one with newNormal's sign.
+__device__ __forceinline__ vec3 reflect_off_face(vec3 I, vec3 n) {
+	const float dn = dot(I, n);
+	const bool keep = dn < 0.0f;                                             // newNormal: dot == 0 flips
+	const vec3 N = keep ? n : n * -1.0f;
+	const float dNI = keep ? dn : -dn;
+	return I - (N * dNI) * 2.0f;
+}
+
 // ---- the render kernel in lockstep form (what launches use unless the state machine is asked for) ---
 // The state machine above exists for divergence in bounce depth: any lane may be at any stage, so every
 // pass of its loop runs the whole stage-transition and shading code.  But the pixels of an 8x8 tile
@@ -1489,7 +1500,7 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 			{
 				float4 N4 = make_float4(0.f, 0.f, 0.f, 0.f);
 				if (bouncing) N4 = sc_hit.planes[PL_N * sc_hit.stride + h.idx];
-				bd = normalize(reflect(d, face_normal(d, xyz(N4))));         // Source.cpp:561, 572
+				bd = normalize(reflect_off_face(d, xyz(N4)));                // Source.cpp:561, 572
 			}
 			while (__builtin_amdgcn_ballot_w64(bouncing) != 0ull) {
 				if constexpr (COUNT) ctr[CTR_BOUNCE] += bouncing;
@@ -1507,7 +1518,7 @@ __global__ void __launch_bounds__(256, ACCEL == 2 ? RT_MIN_WAVES_LBVH : (ACCEL =
 					float4 N4 = make_float4(0.f, 0.f, 0.f, 0.f);
 					if (cont) N4 = sc_hit.planes[PL_N * sc_hit.stride + g.idx];
 					if (cont) {                                              // Source.cpp:576-579
-						bd = normalize(reflect(bd, face_normal(bd, xyz(N4))));
+						bd = normalize(reflect_off_face(bd, xyz(N4)));
 						bo = g.p;
 						bskip = g.idx;
 						bounces++;
