@@ -368,7 +368,8 @@ def roofline_of(flops_per_launch, kernel_ms, fpl, launches, workload, share=1.0)
             "valu_issue_use": issue_use_of(workload, kernel_ms, fpl, share), "profile_source_hash": source_hash(), "profile_stale": stale, "profile_scaled_by": scaled,
             "kernel_ms": kernel_ms, "flops_per_launch": flops_per_launch, "frames_per_launch": fpl, "launches": launches,
             "note": "FP32 VALU roofline (SURVEY 8d): nothing here is HBM- or MFMA-shaped; algorithmic FLOPs = 14/plane + 6/point + "
-                    "17/edge term + 22/box + 32|29|30 per ray, counted in the traversal that is timed; valu_issue_use = share of the SIMDs' "
+                    "17/edge term + 22/box + 32|29|30 per ray, counted in the traversal that is timed (brute force: the reference's own loop over every triangle — "
+                    "the kernel's box tests and sign filters skip part of that work, so frac can pass 1 on a small scene); valu_issue_use = share of the SIMDs' "
                     "vector issue slots the kernel fills in this run (instruction counts of the PMC pass under profiles/ x measured cycles "
                     "per instruction / (1024 SIMDs x kernel cycles)); issued_tflops = VALU FLOPs the kernel really executes per second; "
                     "traffic, issued_tflops and valu_issue_use are null when profiles/ was measured on other sources (profile_stale)"}
